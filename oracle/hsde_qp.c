@@ -1,0 +1,626 @@
+/*
+ * oracle/hsde_qp.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C float64 CPU restatement of the QP relaxation that the reference
+ * solves at every branch-and-bound node, with the reference's sign, status
+ * and infeasibility-certificate conventions.  Only tests/, smoke() and the
+ * cpu_baseline leg of bench.py may call this file.
+ *
+ * What is restated (paths under /root/reference):
+ *   - the QP itself:             warm_start_hmpc/controller.py:119-184
+ *       min sum_t |Q x_t|^2 + |R u_t|^2 + |Q_T x_T|^2
+ *       lam_0   : x_0 == x0
+ *       nu_lb_t : -ub_t <= -lb_t          nu_ub_t : ub_t <= ub_t^max
+ *       lam_t+1 : x_{t+1} == A x_t + B u_t
+ *       mu_t    : F x_t + G u_t <= h      (t = T-1: F_Tm1, G_Tm1, h_Tm1)
+ *   - node -> bounds:            controller.py:273-327 (fixed v => lb = ub = v)
+ *   - status / sign conventions: warm_start_hmpc/bounded_qp.py:200-332
+ *       optimal   : multipliers of "<=" rows are >= 0 (the reference returns -Pi)
+ *       infeasible: objective +inf, primal absent, multipliers = Farkas proof,
+ *                   dual objective = -sum(rhs * farkas) > 0
+ *   - output record:             warm_start_hmpc/subproblem_solution.py:68-168
+ *       rho_t = 2 Q x_t, rho_T = 2 Q_T x_T, sigma_t = 2 R u_t (zeros if infeasible)
+ *
+ * The arithmetic of the reference lives in Gurobi (gurobipy, un-pinned in
+ * setup.py:16-20, proprietary, absent from this image), so it cannot be
+ * restated; it is replaced by a published algorithm: a Mehrotra
+ * predictor-corrector interior point method on the homogeneous embedding of
+ * the QP (Andersen & Ye 1999; the QP form used by Goulart & Chen, "Clarabel",
+ * 2024), with the KKT systems solved by a Riccati recursion over the horizon.
+ * Optimal points and infeasibility proofs are self-certifying (KKT residuals
+ * / Farkas conditions) and the tests check exactly those, so the oracle is
+ * pinned by the reference's own known-answer and property tests
+ * (SURVEY.md 8c); no Gurobi output exists to compare digits with.
+ *
+ * Inequality rows of stage t, in this order:  [F G] rows, then -ub_i <= -lb_i
+ * (i < nub), then ub_i <= ub_i^max.  A fixed binary is not an inequality pair
+ * here: it is the equality ub_i = v with one free multiplier nu = nu_ub-nu_lb,
+ * split afterwards as nu_ub = max(nu,0), nu_lb = max(-nu,0).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ST_OPTIMAL 0
+#define ST_INFEASIBLE 1
+#define ST_MAXITER 2
+#define ST_NUMERICAL 3
+
+typedef struct {
+    int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, nq, nr, nqT;
+    const double *A, *B, *Q, *R, *QT;
+    double *Creg, *hreg, *Clast, *hlast; /* row-scaled, bound rows included */
+    double *sreg, *slast;                /* row scales of the general rows  */
+    double *P, *PT;                      /* 2*cs*(Q'Q (+) R'R), 2*cs*QT'QT   */
+    double cs;                           /* cost scale                       */
+    int *roff;                           /* first row of stage t            */
+} prob_t;
+
+static const double *Ct(const prob_t *p, int t) { return t < p->T - 1 ? p->Creg : p->Clast; }
+static const double *ht(const prob_t *p, int t) { return t < p->T - 1 ? p->hreg : p->hlast; }
+static int mt(const prob_t *p, int t) { return t < p->T - 1 ? p->mreg : p->mlast; }
+
+static void build_stage(const prob_t *p, const double *F, const double *G, const double *h, int nrow,
+                        double *C, double *hh, double *scale)
+{
+    int nx = p->nx, nu = p->nu, nz = p->nz, nub = p->nub, nuc = p->nuc;
+    memset(C, 0, sizeof(double) * (size_t)(nrow + 2 * nub) * nz);
+    for (int r = 0; r < nrow; r++) {
+        double n2 = 0;
+        for (int j = 0; j < nx; j++) n2 += F[r * nx + j] * F[r * nx + j];
+        for (int j = 0; j < nu; j++) n2 += G[r * nu + j] * G[r * nu + j];
+        double sc = n2 > 0 ? 1.0 / sqrt(n2) : 1.0;
+        scale[r] = sc;
+        for (int j = 0; j < nx; j++) C[r * nz + j] = sc * F[r * nx + j];
+        for (int j = 0; j < nu; j++) C[r * nz + nx + j] = sc * G[r * nu + j];
+        hh[r] = sc * h[r];
+    }
+    for (int i = 0; i < nub; i++) {
+        C[(nrow + i) * nz + nx + nuc + i] = -1.0; hh[nrow + i] = 0.0;       /* -ub <= 0 */
+        C[(nrow + nub + i) * nz + nx + nuc + i] = 1.0; hh[nrow + nub + i] = 1.0; /* ub <= 1 */
+    }
+}
+
+static prob_t *prob_create(int nx, int nu, int nub, int T, int nc, int ncL, int nq, int nr, int nqT,
+                           const double *A, const double *B, const double *F, const double *G, const double *h,
+                           const double *FL, const double *GL, const double *hL,
+                           const double *Q, const double *R, const double *QT)
+{
+    prob_t *p = (prob_t *)calloc(1, sizeof(prob_t));
+    p->nx = nx; p->nu = nu; p->nub = nub; p->nuc = nu - nub; p->nz = nx + nu; p->T = T;
+    p->nc = nc; p->ncL = ncL; p->mreg = nc + 2 * nub; p->mlast = ncL + 2 * nub;
+    p->M = (T - 1) * p->mreg + p->mlast; p->nq = nq; p->nr = nr; p->nqT = nqT;
+    p->A = A; p->B = B; p->Q = Q; p->R = R; p->QT = QT;
+    int nz = p->nz;
+    p->Creg = (double *)malloc(sizeof(double) * p->mreg * nz); p->hreg = (double *)malloc(sizeof(double) * p->mreg);
+    p->Clast = (double *)malloc(sizeof(double) * p->mlast * nz); p->hlast = (double *)malloc(sizeof(double) * p->mlast);
+    p->sreg = (double *)malloc(sizeof(double) * (nc + 1)); p->slast = (double *)malloc(sizeof(double) * (ncL + 1));
+    build_stage(p, F, G, h, nc, p->Creg, p->hreg, p->sreg);
+    build_stage(p, FL, GL, hL, ncL, p->Clast, p->hlast, p->slast);
+    p->P = (double *)calloc((size_t)nz * nz, sizeof(double)); p->PT = (double *)calloc((size_t)nx * nx, sizeof(double));
+    /* cost scale: bring the largest Hessian entry to 1 */
+    double big = 0;
+    for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
+        double a = 0, b = 0;
+        for (int k = 0; k < nq; k++) a += Q[k * nx + i] * Q[k * nx + j];
+        for (int k = 0; k < nqT; k++) b += QT[k * nx + i] * QT[k * nx + j];
+        p->P[i * nz + j] = 2 * a; p->PT[i * nx + j] = 2 * b;
+        if (fabs(2 * a) > big) big = fabs(2 * a);
+        if (fabs(2 * b) > big) big = fabs(2 * b);
+    }
+    for (int i = 0; i < nu; i++) for (int j = 0; j < nu; j++) {
+        double a = 0;
+        for (int k = 0; k < nr; k++) a += R[k * nu + i] * R[k * nu + j];
+        p->P[(nx + i) * nz + nx + j] = 2 * a;
+        if (fabs(2 * a) > big) big = fabs(2 * a);
+    }
+    p->cs = big > 0 ? 1.0 / big : 1.0;
+    for (int i = 0; i < nz * nz; i++) p->P[i] *= p->cs;
+    for (int i = 0; i < nx * nx; i++) p->PT[i] *= p->cs;
+    p->roff = (int *)malloc(sizeof(int) * (T + 1));
+    for (int t = 0; t <= T; t++) p->roff[t] = t < T ? t * p->mreg : p->M;
+    return p;
+}
+
+static void prob_free(prob_t *p)
+{
+    free(p->Creg); free(p->hreg); free(p->Clast); free(p->hlast); free(p->sreg); free(p->slast);
+    free(p->P); free(p->PT); free(p->roff); free(p);
+}
+
+/* per-solve workspace */
+typedef struct {
+    double *w, *lam, *nuf, *s, *z;           /* iterate: w = [w_0..w_{T-1} | x_T]              */
+    double *D, *Phi, *L, *Kx, *Pr, *mb;      /* factorisation                                  */
+    double *rd, *rdyn, *rc;                  /* residuals                                      */
+    double *g, *rhs_c, *pvec, *lu;           /* solve scratch                                  */
+    double *w1, *lam1, *nuf1, *z1;           /* constant direction                             */
+    double *w2, *lam2, *nuf2, *z2;           /* residual direction (affine, then corrector)    */
+    double *dsa, *dza;                       /* affine slack / multiplier steps                */
+    double *Pw, *sd, *sc;
+    unsigned char *act;
+} work_t;
+
+static work_t *work_create(const prob_t *p)
+{
+    work_t *k = (work_t *)calloc(1, sizeof(work_t));
+    int nz = p->nz, nx = p->nx, nu = p->nu, T = p->T, M = p->M, n = T * nz + nx;
+#define AL(name, cnt) k->name = (double *)calloc((size_t)(cnt), sizeof(double))
+    AL(w, n); AL(lam, (T + 1) * nx); AL(nuf, T * p->nub); AL(s, M); AL(z, M);
+    AL(D, M); AL(Phi, (size_t)T * nz * nz); AL(L, (size_t)T * nu * nu); AL(Kx, (size_t)T * nu * nx);
+    AL(Pr, (size_t)(T + 1) * nx * nx); AL(mb, (size_t)T * nz);
+    AL(rd, n); AL(rdyn, T * nx); AL(rc, M); AL(g, n); AL(rhs_c, M); AL(pvec, (T + 1) * nx); AL(lu, T * nu);
+    AL(w1, n); AL(lam1, (T + 1) * nx); AL(nuf1, T * p->nub); AL(z1, M);
+    AL(w2, n); AL(lam2, (T + 1) * nx); AL(nuf2, T * p->nub); AL(z2, M);
+    AL(dsa, M); AL(dza, M); AL(Pw, n); AL(sd, n); AL(sc, T * nx);
+#undef AL
+    k->act = (unsigned char *)calloc((size_t)M, 1);
+    return k;
+}
+
+static void work_free(work_t *k)
+{
+    free(k->w); free(k->lam); free(k->nuf); free(k->s); free(k->z); free(k->D); free(k->Phi); free(k->L);
+    free(k->Kx); free(k->Pr); free(k->mb); free(k->rd); free(k->rdyn); free(k->rc); free(k->g); free(k->rhs_c);
+    free(k->pvec); free(k->lu); free(k->w1); free(k->lam1); free(k->nuf1); free(k->z1); free(k->w2);
+    free(k->lam2); free(k->nuf2); free(k->z2); free(k->dsa); free(k->dza); free(k->Pw); free(k->sd); free(k->sc); free(k->act); free(k);
+}
+
+/* Riccati factorisation of  Phi_t = P + C_t' D C_t  along the horizon.
+ * fix[t*nub+i] in {-1 free, 0, 1}; a fixed binary is a prescribed variable. */
+static int factor(const prob_t *p, work_t *k, const int8_t *fix)
+{
+    int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub;
+    double Mm[64 * 64], PA[32 * 64];
+    memcpy(k->Pr + (size_t)T * nx * nx, p->PT, sizeof(double) * nx * nx);
+    for (int t = T - 1; t >= 0; t--) {
+        const double *C = Ct(p, t); int m = mt(p, t); const double *D = k->D + p->roff[t];
+        const double *Pn = k->Pr + (size_t)(t + 1) * nx * nx;
+        /* M = P + C' D C */
+        for (int i = 0; i < nz; i++) for (int j = 0; j <= i; j++) {
+            double a = p->P[i * nz + j];
+            for (int r = 0; r < m; r++) { double ci = C[r * nz + i]; if (ci != 0.0) a += ci * D[r] * C[r * nz + j]; }
+            Mm[i * nz + j] = a; Mm[j * nz + i] = a;
+        }
+        /* PA = Pn [A B] (nx x nz) ;  M += [A B]' PA */
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nz; j++) {
+            double a = 0;
+            for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * (j < nx ? p->A[l * nx + j] : p->B[l * nu + (j - nx)]);
+            PA[i * nz + j] = a;
+        }
+        for (int i = 0; i < nz; i++) for (int j = 0; j <= i; j++) {
+            double a = 0;
+            for (int l = 0; l < nx; l++) a += (i < nx ? p->A[l * nx + i] : p->B[l * nu + (i - nx)]) * PA[l * nz + j];
+            Mm[i * nz + j] += a; if (i != j) Mm[j * nz + i] += a;
+        }
+        /* prescribed (fixed) binaries */
+        double *mb = k->mb + (size_t)t * nz;
+        for (int i = 0; i < nz; i++) mb[i] = 0;
+        for (int b = 0; b < nub; b++) if (fix[t * nub + b] == 1) {
+            int c = nx + nuc + b;
+            for (int i = 0; i < nz; i++) mb[i] += Mm[i * nz + c];
+        }
+        for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) {
+            int c = nx + nuc + b;
+            for (int i = 0; i < nz; i++) { Mm[i * nz + c] = 0; Mm[c * nz + i] = 0; }
+            Mm[c * nz + c] = 1.0;
+        }
+        /* Cholesky of M_uu */
+        double *L = k->L + (size_t)t * nu * nu, *Kx = k->Kx + (size_t)t * nu * nx;
+        for (int j = 0; j < nu; j++) {
+            double d = Mm[(nx + j) * nz + nx + j];
+            for (int l = 0; l < j; l++) d -= L[j * nu + l] * L[j * nu + l];
+            if (!(d > 0)) return -1;
+            d = sqrt(d); L[j * nu + j] = d;
+            for (int i = j + 1; i < nu; i++) {
+                double a = Mm[(nx + i) * nz + nx + j];
+                for (int l = 0; l < j; l++) a -= L[i * nu + l] * L[j * nu + l];
+                L[i * nu + j] = a / d;
+            }
+        }
+        /* Kx = L^{-1} M_ux */
+        for (int c = 0; c < nx; c++) for (int i = 0; i < nu; i++) {
+            double a = Mm[(nx + i) * nz + c];
+            for (int l = 0; l < i; l++) a -= L[i * nu + l] * Kx[l * nx + c];
+            Kx[i * nx + c] = a / L[i * nu + i];
+        }
+        double *Pt = k->Pr + (size_t)t * nx * nx;
+        for (int i = 0; i < nx; i++) for (int j = 0; j < nx; j++) {
+            double a = Mm[i * nz + j];
+            for (int l = 0; l < nu; l++) a -= Kx[l * nx + i] * Kx[l * nx + j];
+            Pt[i * nx + j] = a;
+        }
+    }
+    return 0;
+}
+
+/* Solves K v = rhs for one right-hand side.
+ *   rhs_d : n (stage gradients), may be NULL (= 0)
+ *   a     : prescribed x_0 (nx), may be NULL
+ *   cdyn  : T*nx dynamics offsets, may be NULL
+ *   useb  : prescribed value of fixed binary = its v (1) or 0 (0)
+ *   rhs_c : M
+ * outputs dw (n), dlam ((T+1)nx), dnuf (T nub), dz (M)                          */
+static void kkt_solve(const prob_t *p, work_t *k, const int8_t *fix, const double *rhs_d, const double *a,
+                      const double *cdyn, int useb, const double *rhs_c,
+                      double *dw, double *dlam, double *dnuf, double *dz)
+{
+    int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub;
+    double *g = k->g, *pv = k->pvec;
+    double q[64], mv[128];
+    /* g = rhs_d + C' (D rhs_c) */
+    for (int t = 0; t < T; t++) {
+        const double *C = Ct(p, t); int m = mt(p, t); int ro = p->roff[t];
+        for (int j = 0; j < nz; j++) g[t * nz + j] = rhs_d ? rhs_d[t * nz + j] : 0.0;
+        for (int r = 0; r < m; r++) if (k->act[ro + r]) {
+            double e = k->D[ro + r] * rhs_c[ro + r];
+            for (int j = 0; j < nz; j++) g[t * nz + j] += C[r * nz + j] * e;
+        }
+    }
+    for (int j = 0; j < nx; j++) { g[T * nz + j] = rhs_d ? rhs_d[T * nz + j] : 0.0; pv[T * nx + j] = -g[T * nz + j]; }
+    /* backward */
+    for (int t = T - 1; t >= 0; t--) {
+        const double *Pn = k->Pr + (size_t)(t + 1) * nx * nx;
+        const double *L = k->L + (size_t)t * nu * nu, *Kx = k->Kx + (size_t)t * nu * nx;
+        for (int i = 0; i < nx; i++) {
+            double s = pv[(t + 1) * nx + i];
+            if (cdyn) for (int l = 0; l < nx; l++) s += Pn[i * nx + l] * cdyn[t * nx + l];
+            q[i] = s;
+        }
+        for (int j = 0; j < nz; j++) {
+            double s = -g[t * nz + j];
+            for (int l = 0; l < nx; l++) s += (j < nx ? p->A[l * nx + j] : p->B[l * nu + (j - nx)]) * q[l];
+            if (useb) s += k->mb[t * nz + j];
+            mv[j] = s;
+        }
+        for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0)
+            mv[nx + nuc + b] = (useb && fix[t * nub + b] == 1) ? -1.0 : 0.0;
+        double *lu = k->lu + (size_t)t * nu;
+        for (int i = 0; i < nu; i++) {
+            double s = mv[nx + i];
+            for (int l = 0; l < i; l++) s -= L[i * nu + l] * lu[l];
+            lu[i] = s / L[i * nu + i];
+        }
+        for (int i = 0; i < nx; i++) {
+            double s = mv[i];
+            for (int l = 0; l < nu; l++) s -= Kx[l * nx + i] * lu[l];
+            pv[t * nx + i] = s;
+        }
+    }
+    /* forward */
+    for (int i = 0; i < nx; i++) dw[i] = a ? a[i] : 0.0;
+    for (int t = 0; t < T; t++) {
+        const double *L = k->L + (size_t)t * nu * nu, *Kx = k->Kx + (size_t)t * nu * nx;
+        const double *lu = k->lu + (size_t)t * nu;
+        double *x = dw + t * nz, *u = dw + t * nz + nx, *xn = dw + (t + 1) * nz;
+        double v[64];
+        for (int i = 0; i < nu; i++) {
+            double s = lu[i];
+            for (int l = 0; l < nx; l++) s += Kx[i * nx + l] * x[l];
+            v[i] = -s;
+        }
+        for (int i = nu - 1; i >= 0; i--) {
+            double s = v[i];
+            for (int l = i + 1; l < nu; l++) s -= L[l * nu + i] * u[l];
+            u[i] = s / L[i * nu + i];
+        }
+        for (int i = 0; i < nx; i++) {
+            double s = cdyn ? cdyn[t * nx + i] : 0.0;
+            for (int l = 0; l < nx; l++) s += p->A[i * nx + l] * x[l];
+            for (int l = 0; l < nu; l++) s += p->B[i * nu + l] * u[l];
+            xn[i] = s;
+        }
+    }
+    /* multipliers of the equalities: lam_t = -(P_t x_t + p_t) */
+    for (int t = 0; t <= T; t++) {
+        const double *Pt = k->Pr + (size_t)t * nx * nx; const double *x = dw + t * nz;
+        for (int i = 0; i < nx; i++) {
+            double s = pv[t * nx + i];
+            for (int l = 0; l < nx; l++) s += Pt[i * nx + l] * x[l];
+            dlam[t * nx + i] = -s;
+        }
+    }
+    /* dz = D (C dw - rhs_c) */
+    for (int t = 0; t < T; t++) {
+        const double *C = Ct(p, t); int m = mt(p, t); int ro = p->roff[t];
+        for (int r = 0; r < m; r++) {
+            if (!k->act[ro + r]) { dz[ro + r] = 0; continue; }
+            double s = -rhs_c[ro + r];
+            for (int j = 0; j < nz; j++) s += C[r * nz + j] * dw[t * nz + j];
+            dz[ro + r] = k->D[ro + r] * s;
+        }
+    }
+    /* multipliers of the fixed binaries from stationarity of their component */
+    for (int t = 0; t < T; t++) {
+        const double *C = Ct(p, t); int m = mt(p, t); int ro = p->roff[t];
+        for (int b = 0; b < nub; b++) {
+            if (fix[t * nub + b] < 0) { dnuf[t * nub + b] = 0; continue; }
+            int c = nx + nuc + b;
+            double s = rhs_d ? rhs_d[t * nz + c] : 0.0;
+            for (int j = 0; j < nz; j++) s -= p->P[c * nz + j] * dw[t * nz + j];
+            for (int r = 0; r < m; r++) s -= C[r * nz + c] * dz[ro + r];
+            for (int l = 0; l < nx; l++) s += p->B[l * nu + (c - nx)] * dlam[(t + 1) * nx + l];
+            dnuf[t * nub + b] = s;
+        }
+    }
+}
+
+static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i < n; i++) if (fabs(v[i]) > m) m = fabs(v[i]); return m; }
+
+/* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
+static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, double tol, double tol_inf, int max_iter,
+                     double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol)
+{
+    int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
+    int mact = 0;
+    for (int t = 0; t < T; t++) {
+        int m = mt(p, t), mg = m - 2 * nub, ro = p->roff[t];
+        for (int r = 0; r < m; r++) {
+            int on = 1;
+            if (r >= mg) on = fix[t * nub + ((r - mg) % nub)] < 0;
+            else if (!term_on && t == T - 1 && r >= p->nc) on = 0;   /* terminal-set rows masked */
+            k->act[ro + r] = (unsigned char)on; mact += on;
+            k->s[ro + r] = 1.0; k->z[ro + r] = on ? 1.0 : 0.0;
+        }
+    }
+    memset(k->w, 0, sizeof(double) * n); memset(k->lam, 0, sizeof(double) * (T + 1) * nx);
+    memset(k->nuf, 0, sizeof(double) * T * nub);
+    double tau = 1.0, kap = 1.0;
+    /* prescribed components follow tau exactly */
+    for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
+    for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
+
+    int status = ST_MAXITER, it = 0;
+    double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
+    double x0inf = vmaxabs(x0, nx);
+    (void)hinf;
+    for (it = 0; it <= max_iter; it++) {
+        /* ---- residuals ---- */
+        double wPw = 0, fy = 0, hz = 0, sz = 0;
+        for (int t = 0; t <= T; t++) {
+            int dim = t < T ? nz : nx; const double *PP = t < T ? p->P : p->PT;
+            for (int i = 0; i < dim; i++) {
+                double s = 0;
+                for (int j = 0; j < dim; j++) s += PP[i * dim + j] * k->w[t * nz + j];
+                k->Pw[t * nz + i] = s; wPw += s * k->w[t * nz + i];
+            }
+        }
+        for (int t = 0; t < T; t++) {
+            const double *C = Ct(p, t); const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+            double *rd = k->rd + t * nz;
+            for (int j = 0; j < nz; j++) rd[j] = k->Pw[t * nz + j];
+            for (int j = 0; j < nx; j++) {
+                double s = k->lam[t * nx + j];
+                for (int l = 0; l < nx; l++) s -= p->A[l * nx + j] * k->lam[(t + 1) * nx + l];
+                rd[j] += s;
+            }
+            for (int j = 0; j < nu; j++) {
+                double s = 0;
+                for (int l = 0; l < nx; l++) s -= p->B[l * nu + j] * k->lam[(t + 1) * nx + l];
+                rd[nx + j] += s;
+            }
+            for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) { rd[nx + nuc + b] += k->nuf[t * nub + b]; fy += fix[t * nub + b] * k->nuf[t * nub + b]; }
+            for (int r = 0; r < m; r++) {
+                if (!k->act[ro + r]) { k->rc[ro + r] = 0; continue; }
+                double zr = k->z[ro + r], s = k->s[ro + r] - hh[r] * tau;
+                for (int j = 0; j < nz; j++) { double c = C[r * nz + j]; if (c != 0.0) { rd[j] += c * zr; s += c * k->w[t * nz + j]; } }
+                k->rc[ro + r] = s; hz += hh[r] * zr; sz += k->s[ro + r] * zr;
+            }
+            for (int i = 0; i < nx; i++) {
+                double s = k->w[(t + 1) * nz + i];
+                for (int l = 0; l < nx; l++) s -= p->A[i * nx + l] * k->w[t * nz + l];
+                for (int l = 0; l < nu; l++) s -= p->B[i * nu + l] * k->w[t * nz + nx + l];
+                k->rdyn[t * nx + i] = s;
+            }
+        }
+        for (int j = 0; j < nx; j++) { k->rd[T * nz + j] = k->Pw[T * nz + j] + k->lam[T * nx + j]; fy += x0[j] * k->lam[j]; }
+        double rg = wPw / tau + fy + hz + kap;
+        double mu = (sz + tau * kap) / (mact + 1);
+
+        /* ---- termination ---- */
+        double rdinf = vmaxabs(k->rd, n), rcinf = fmax(vmaxabs(k->rc, M), vmaxabs(k->rdyn, T * nx));
+        double winf = vmaxabs(k->w, n) / tau, zinf = fmax(vmaxabs(k->z, M), fmax(vmaxabs(k->lam, (T + 1) * nx), vmaxabs(k->nuf, T * nub))) / tau;
+        double pobj = 0.5 * wPw / (tau * tau), dob = -0.5 * wPw / (tau * tau) - (fy + hz) / tau;
+        double gap = fabs(pobj - dob);
+        if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e pobj %.6e eta %.3e\n", it, tau, kap, mu, rcinf / tau, rdinf / tau, gap, pobj, -(fy + hz));
+        if (rcinf / tau <= tol * (1 + winf + x0inf) && rdinf / tau <= tol * (1 + zinf) && gap <= tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
+            status = ST_OPTIMAL; break;
+        }
+        {   /* Farkas: E'y + C'z = rd - Pw, -(f'y + h'z) > 0 */
+            double eta = -(fy + hz), cert = 0;
+            for (int i = 0; i < n; i++) { double v = fabs(k->rd[i] - k->Pw[i]); if (v > cert) cert = v; }
+            if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      cert %.3e eta %.3e zinf %.3e raw rd %.3e rc %.3e\n", cert, eta, zinf * tau, rdinf, rcinf);
+            /* (a) clean proof; (b) tau has collapsed against kappa: in exact arithmetic that alone
+             * means "no optimum", and the proof is as accurate as double precision allows */
+            if (eta > 0 && (cert <= tol_inf * eta || (tau <= 1e-8 * kap && cert <= 1e-3 * eta))) { status = ST_INFEASIBLE; break; }
+        }
+        if (it == max_iter) break;
+
+        /* ---- factorisation ---- */
+        for (int r = 0; r < M; r++) k->D[r] = k->act[r] ? k->z[r] / k->s[r] : 0.0;
+        if (factor(p, k, fix) != 0) { status = ST_NUMERICAL; break; }
+
+        /* ---- constant direction: rhs = (0; f; h) ---- */
+        for (int t = 0; t < T; t++) { const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t]; for (int r = 0; r < m; r++) k->rhs_c[ro + r] = hh[r]; }
+        kkt_solve(p, k, fix, NULL, x0, NULL, 1, k->rhs_c, k->w1, k->lam1, k->nuf1, k->z1);
+        double g1 = 0, fy1 = 0, hz1 = 0;
+        for (int i = 0; i < n; i++) g1 += k->Pw[i] * k->w1[i];
+        g1 *= 2.0 / tau;
+        for (int j = 0; j < nx; j++) fy1 += x0[j] * k->lam1[j];
+        for (int t = 0; t < T; t++) {
+            const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+            for (int b = 0; b < nub; b++) if (fix[t * nub + b] == 1) fy1 += k->nuf1[t * nub + b];
+            for (int r = 0; r < m; r++) if (k->act[ro + r]) hz1 += hh[r] * k->z1[ro + r];
+        }
+        double den = kap / tau + wPw / (tau * tau) - g1 - fy1 - hz1;
+
+        double dtau_a = 0, dkap_a = 0, sigma = 0, alpha = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            double lin = pass == 0 ? 1.0 : 1.0 - sigma;
+            double dkap_rhs = tau * kap + (pass ? dtau_a * dkap_a - sigma * mu : 0.0);
+            /* rhs_d = -lin rd ; cdyn = -lin rdyn ; rhs_c = -lin rc + ds/z */
+            double *sd = k->sd, *sc = k->sc;
+            for (int i = 0; i < n; i++) sd[i] = -lin * k->rd[i];
+            for (int i = 0; i < T * nx; i++) sc[i] = -lin * k->rdyn[i];
+            for (int r = 0; r < M; r++) {
+                if (!k->act[r]) { k->rhs_c[r] = 0; continue; }
+                double ds = k->s[r] * k->z[r] + (pass ? k->dsa[r] * k->dza[r] - sigma * mu : 0.0);
+                k->rhs_c[r] = -lin * k->rc[r] + ds / k->z[r];
+            }
+            kkt_solve(p, k, fix, sd, NULL, sc, 0, k->rhs_c, k->w2, k->lam2, k->nuf2, k->z2);
+            double g2 = 0, fy2 = 0, hz2 = 0;
+            for (int i = 0; i < n; i++) g2 += k->Pw[i] * k->w2[i];
+            g2 *= 2.0 / tau;
+            for (int j = 0; j < nx; j++) fy2 += x0[j] * k->lam2[j];
+            for (int t = 0; t < T; t++) {
+                const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+                for (int b = 0; b < nub; b++) if (fix[t * nub + b] == 1) fy2 += k->nuf2[t * nub + b];
+                for (int r = 0; r < m; r++) if (k->act[ro + r]) hz2 += hh[r] * k->z2[ro + r];
+            }
+            double dtau = (lin * rg - dkap_rhs / tau + g2 + fy2 + hz2) / den;
+            double dkap = -(dkap_rhs + kap * dtau) / tau;
+            /* combine and step length */
+            double amax = 1e30;
+            if (dtau < 0) amax = fmin(amax, -tau / dtau);
+            if (dkap < 0) amax = fmin(amax, -kap / dkap);
+            for (int r = 0; r < M; r++) {
+                if (!k->act[r]) { k->z2[r] = 0; k->dsa[r] = 0; continue; }
+                double dz = k->z2[r] + dtau * k->z1[r];
+                double dsr = k->s[r] * k->z[r] + (pass ? k->dsa[r] * k->dza[r] - sigma * mu : 0.0);
+                double ds = -(dsr + k->s[r] * dz) / k->z[r];
+                if (dz < 0) amax = fmin(amax, -k->z[r] / dz);
+                if (ds < 0) amax = fmin(amax, -k->s[r] / ds);
+                k->z2[r] = dz;
+                if (pass == 0) { k->dza[r] = dz; k->dsa[r] = ds; } else k->rhs_c[r] = ds; /* rhs_c reused as ds */
+            }
+            if (pass == 0) {
+                double aa = fmin(1.0, amax);
+                sigma = (1 - aa) * (1 - aa) * (1 - aa);
+                dtau_a = dtau; dkap_a = dkap;
+            } else {
+                alpha = fmin(1.0, 0.99 * amax);
+                if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      sigma %.3e alpha %.3e dtau %.3e\n", sigma, alpha, dtau);
+                for (int i = 0; i < n; i++) k->w[i] += alpha * (k->w2[i] + dtau * k->w1[i]);
+                for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] += alpha * (k->lam2[i] + dtau * k->lam1[i]);
+                for (int i = 0; i < T * nub; i++) k->nuf[i] += alpha * (k->nuf2[i] + dtau * k->nuf1[i]);
+                for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] += alpha * k->z2[r]; k->s[r] += alpha * k->rhs_c[r]; }
+                tau += alpha * dtau; kap += alpha * dkap;
+                for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
+                for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
+            }
+        }
+        if (!(tau > 0) || !(kap >= 0) || tau != tau) { status = ST_NUMERICAL; break; }
+    }
+    *iters = it;
+
+    /* ---- outputs in the reference's conventions ---- */
+    int nmu = (T - 1) * p->nc + p->ncL;
+    double *lam_o = dual, *mu_o = dual + (T + 1) * nx, *nlb_o = mu_o + nmu, *nub_o = nlb_o + T * nub;
+    double *rho_o = nub_o + T * nub, *sig_o = rho_o + T * p->nq + p->nqT;
+    int nd = (T + 1) * nx + nmu + 2 * T * nub + T * p->nq + p->nqT + T * p->nr;
+    double *x_o = primal, *u_o = primal + (T + 1) * nx;
+    double scale;
+    if (status == ST_INFEASIBLE) {
+        double big = fmax(vmaxabs(k->z, M), fmax(vmaxabs(k->lam, (T + 1) * nx), vmaxabs(k->nuf, T * nub)));
+        scale = 1.0 / big;   /* Farkas ray: scale is arbitrary, normalise the largest scaled multiplier to 1 */
+    } else scale = 1.0 / (tau * p->cs);
+    for (int i = 0; i < nd; i++) dual[i] = 0;
+    for (int i = 0; i < (T + 1) * nx; i++) lam_o[i] = k->lam[i] * scale;
+    double farkas = 0;
+    for (int j = 0; j < nx; j++) farkas -= x0[j] * lam_o[j];
+    for (int t = 0; t < T; t++) {
+        int m = mt(p, t), mg = m - 2 * nub, ro = p->roff[t]; const double *sc = t < T - 1 ? p->sreg : p->slast;
+        const double *hh = ht(p, t);
+        for (int r = 0; r < mg; r++) { double v = k->z[ro + r] * scale * sc[r]; mu_o[t * p->nc + r] = v; farkas -= (hh[r] / sc[r]) * v; }
+        for (int b = 0; b < nub; b++) {
+            double lo, hi;
+            if (fix[t * nub + b] < 0) { lo = k->z[ro + mg + b] * scale; hi = k->z[ro + mg + nub + b] * scale; farkas -= hi; }
+            else { double v = k->nuf[t * nub + b] * scale; hi = v > 0 ? v : 0; lo = v < 0 ? -v : 0; farkas -= fix[t * nub + b] * (hi - lo); }
+            nlb_o[t * nub + b] = lo; nub_o[t * nub + b] = hi;
+        }
+    }
+    *term_viol = 0;
+    if (status == ST_INFEASIBLE) {
+        for (int i = 0; i < (T + 1) * nx + T * nu; i++) primal[i] = NAN;
+        *obj = INFINITY; *dobj = farkas;
+    } else {
+        double cost = 0;
+        for (int t = 0; t <= T; t++) for (int i = 0; i < nx; i++) x_o[t * nx + i] = k->w[t * nz + i] / tau;
+        for (int t = 0; t < T; t++) for (int i = 0; i < nu; i++) u_o[t * nu + i] = k->w[t * nz + nx + i] / tau;
+        for (int t = 0; t <= T; t++) {
+            const double *QQ = t < T ? p->Q : p->QT; int rows = t < T ? p->nq : p->nqT;
+            double *rho = rho_o + t * p->nq;
+            for (int r = 0; r < rows; r++) {
+                double s = 0;
+                for (int j = 0; j < nx; j++) s += QQ[r * nx + j] * x_o[t * nx + j];
+                rho[r] = 2 * s; cost += s * s;
+            }
+        }
+        for (int t = 0; t < T; t++) for (int r = 0; r < p->nr; r++) {
+            double s = 0;
+            for (int j = 0; j < nu; j++) s += p->R[r * nu + j] * u_o[t * nu + j];
+            sig_o[t * p->nr + r] = 2 * s; cost += s * s;
+        }
+        *obj = cost;
+        /* largest value of (scaled terminal row) - h over the terminal-set rows */
+        double tv = -INFINITY;
+        for (int r = p->nc; r < p->ncL; r++) {
+            double a = -p->hlast[r] * tau;
+            for (int j = 0; j < nz; j++) a += p->Clast[r * nz + j] * k->w[(T - 1) * nz + j];
+            if (a / tau > tv) tv = a / tau;
+        }
+        *term_viol = tv;
+        /* dual objective of SURVEY.md Appendix A.3 from the multipliers themselves */
+        double dq = 0;
+        for (int i = 0; i < T * p->nq + p->nqT; i++) dq += rho_o[i] * rho_o[i];
+        for (int i = 0; i < T * p->nr; i++) dq += sig_o[i] * sig_o[i];
+        *dobj = -0.25 * dq + farkas;
+    }
+    return status;
+}
+
+/* ---- C entry point used through ctypes ---- */
+int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, int nr, int nqT,
+                       const double *A, const double *B, const double *F, const double *G, const double *h,
+                       const double *FL, const double *GL, const double *hL,
+                       const double *Q, const double *R, const double *QT,
+                       const double *x0, int x0_stride, int nbatch, const int8_t *fix,
+                       double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal,
+                       double *obj, double *dobj, int *status, int *iters, double *primal, double *dual)
+{
+    if (nx + nu > 64 || nx > 32) return -1;
+    prob_t *p = prob_create(nx, nu, nub, T, nc, ncL, nq, nr, nqT, A, B, F, G, h, FL, GL, hL, Q, R, QT);
+    int np_ = (T + 1) * nx + T * nu;
+    int nd = (T + 1) * nx + (T - 1) * nc + ncL + 2 * T * nub + T * nq + nqT + T * nr;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    (void)nthreads;
+#pragma omp parallel
+    {
+        work_t *k = work_create(p);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < nbatch; b++) {
+            /* Lazy terminal set: first without the terminal-set rows.  An infeasibility proof found
+             * there is a proof for the node and carries no terminal multipliers (it survives the
+             * warm-start shift); an optimum that satisfies the masked rows strictly is the optimum
+             * of the node.  Otherwise solve again with every row. */
+            const double *xb = x0 + (size_t)b * x0_stride; const int8_t *fb = fix + (size_t)b * T * nub;
+            double *pb = primal + (size_t)b * np_, *db = dual + (size_t)b * nd, tv = 0; int it1 = 0, it2 = 0, st;
+            if (ncL > nc && lazy_terminal) {
+                st = solve_one(p, k, xb, fb, 0, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
+                if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)))
+                    st = solve_one(p, k, xb, fb, 1, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv);
+            } else st = solve_one(p, k, xb, fb, 1, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
+            status[b] = st; iters[b] = it1 + it2;
+        }
+        work_free(k);
+    }
+    prob_free(p);
+    return 0;
+}

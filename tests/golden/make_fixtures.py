@@ -1,0 +1,114 @@
+"""Regenerates the problem-data fixtures in this directory.
+
+Runs ONLY in the build container (it imports the reference's offline
+modelling code from /root/reference, which does not exist on the GPU box).
+The fixtures are data -- MLD matrices, weights, terminal sets -- and are the
+*inputs* of the hot path; nothing of the reference's source is stored.
+
+    python tests/golden/make_fixtures.py
+
+Outputs
+  cart_pole_with_walls.npz : the benchmark system of BASELINE.json
+      (reference: notebooks/cart_pole_with_walls/{mld_dynamics,controller}.py)
+  cart_pole_one_wall.npz   : the system used by the reference's own tests
+      (reference: warm_start_hmpc/test/cart_pole_with_wall.py:13-116)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'))
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, 'notebooks', 'cart_pole_with_walls'))
+
+# `mld_dynamics.py:8` imports one unused symbol from a package that is absent
+# here; give it an empty stand-in module so the import statement succeeds.
+for name in ('pympc', 'pympc.dynamics', 'pympc.dynamics.discretization_methods'):
+    sys.modules[name] = types.ModuleType(name)
+sys.modules['pympc.dynamics.discretization_methods'].zero_order_hold = None
+
+from warm_start_hmpc_amd.terminal_set import solve_dare, mcais, update_mu  # noqa: E402
+
+
+def two_walls():
+    import mld_dynamics as md  # reference modelling (sympy -> matrices)
+    mld = md.mld
+    h = md.h
+    T = 20
+    Q = np.eye(mld.nx) * h
+    R = np.vstack([1.] + [0.] * (mld.nu - 1)).T * h
+    Bu, Ru = mld.B[:, :1], R[:, :1]
+    P, K = solve_dare(mld.A, Bu, Q.dot(Q), Ru.dot(Ru))
+    Q_T = np.linalg.cholesky(P).T
+    A_cl = mld.A + Bu.dot(K)
+    F_T, h_T = mcais(A_cl, mld.F + mld.G[:, :1].dot(K), mld.h, verbose=True)
+    F_Tm1 = np.vstack((mld.F, F_T.dot(mld.A)))
+    G_Tm1 = np.vstack((mld.G, F_T.dot(mld.B)))
+    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1)
+    np.savez(os.path.join(HERE, 'cart_pole_with_walls.npz'),
+             A=np.array(mld.A, dtype=float), B=np.array(mld.B, dtype=float),
+             F=np.array(mld.F, dtype=float), G=np.array(mld.G, dtype=float),
+             h=np.array(mld.h, dtype=float), nub=mld.nub, T=T,
+             Q=Q, R=R, Q_T=Q_T, F_T=F_T, h_T=h_T, M=M, K=K,
+             x_max=np.array(md.x_max, dtype=float))
+    print('two walls:', mld.F.shape, 'terminal facets', F_T.shape[0])
+
+
+def one_wall():
+    import sympy as sp
+    from warm_start_hmpc.mld_system import MLDSystem  # reference modelling
+    mc, mp, ell, d, k, nu, g, dt = 1., 1., 1., .5, 100., 30., 10., .05
+    x = sp.Matrix(sp.symbols('q t qd td'))
+    u = sp.Matrix([sp.symbols('u')])
+    f = sp.Matrix([sp.symbols('f')])
+    b = sp.Matrix(sp.symbols('el dam'))
+    inputs = sp.Matrix([u, f, b])
+    dyn = sp.Matrix([
+        x[0] + dt * x[2],
+        x[1] + dt * x[3],
+        x[2] + dt * (x[1] * g * mp / mc + u[0] / mc),
+        x[3] + dt * (x[1] * g * (mc + mp) / (ell * mc) + u[0] / (ell * mc) + f[0] / (ell * mp)),
+    ])
+    x_max = np.array([d, np.pi / 8., 2., 1.])
+    u_max = 2.
+    pen = x[0] - ell * x[1] - d
+    pen_d = x[2] - ell * x[3]
+    p_lo, p_hi = -x_max[0] - ell * x_max[1] - d, x_max[0] + ell * x_max[1] - d
+    pd_lo, pd_hi = -x_max[2] - ell * x_max[3], x_max[2] + ell * x_max[3]
+    f_lo, f_hi = k * p_lo + nu * pd_lo, k * p_hi + nu * pd_hi
+    spring = k * pen + nu * pen_d
+    rows = [x[i] - x_max[i] for i in range(4)] + [-x_max[i] - x[i] for i in range(4)]
+    rows += [u[0] - u_max, -u_max - u[0]]
+    rows += [
+        p_lo * (1. - b[0]) - pen, pen - p_hi * b[0],          # el  <-> penetration
+        f_lo * (1. - b[1]) - spring, spring - f_hi * b[1],    # dam <-> pushing force
+        -f[0], f[0] - f_hi * b[0], f[0] - f_hi * b[1],        # no contact -> no force
+        spring + nu * pd_hi * (b[0] - 1.) - f[0],             # contact -> spring-damper
+        f[0] - spring - f_lo * (b[1] - 1.),
+    ]
+    mld = MLDSystem.from_symbolic(dyn, sp.Matrix(rows), x, inputs, 2)
+    T = 40
+    Q = np.eye(mld.nx)
+    R = np.vstack([1.] + [0.] * (mld.nu - 1)).T
+    Q_T = 1.1 * Q
+    F_T = np.vstack((np.eye(mld.nx), -np.eye(mld.nx)))
+    h_T = np.concatenate((x_max, x_max)) / 1.1
+    F_Tm1 = np.vstack((mld.F, F_T.dot(mld.A)))
+    G_Tm1 = np.vstack((mld.G, F_T.dot(mld.B)))
+    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1)
+    np.savez(os.path.join(HERE, 'cart_pole_one_wall.npz'),
+             A=np.array(mld.A, dtype=float), B=np.array(mld.B, dtype=float),
+             F=np.array(mld.F, dtype=float), G=np.array(mld.G, dtype=float),
+             h=np.array(mld.h, dtype=float), nub=mld.nub, T=T,
+             Q=Q, R=R, Q_T=Q_T, F_T=F_T, h_T=h_T, M=M, x_max=x_max)
+    print('one wall:', mld.F.shape, mld.G.shape)
+
+
+if __name__ == '__main__':
+    two_walls()
+    one_wall()
