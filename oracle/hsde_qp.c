@@ -142,7 +142,7 @@ typedef struct {
     double *w1, *lam1, *nuf1, *z1;           /* constant direction                             */
     double *w2, *lam2, *nuf2, *z2;           /* residual direction (affine, then corrector)    */
     double *dsa, *dza;                       /* affine slack / multiplier steps                */
-    double *Pw, *sd, *sc;
+    double *Pw, *sd, *sc, *ed, *edyn, *ec;
     unsigned char *act;
 } work_t;
 
@@ -157,7 +157,7 @@ static work_t *work_create(const prob_t *p)
     AL(rd, n); AL(rdyn, T * nx); AL(rc, M); AL(g, n); AL(rhs_c, M); AL(pvec, (T + 1) * nx); AL(lu, T * nu);
     AL(w1, n); AL(lam1, (T + 1) * nx); AL(nuf1, T * p->nub); AL(z1, M);
     AL(w2, n); AL(lam2, (T + 1) * nx); AL(nuf2, T * p->nub); AL(z2, M);
-    AL(dsa, M); AL(dza, M); AL(Pw, n); AL(sd, n); AL(sc, T * nx);
+    AL(dsa, M); AL(dza, M); AL(Pw, n); AL(sd, n); AL(sc, T * nx); AL(ed, n); AL(edyn, T * nx); AL(ec, M);
 #undef AL
     k->act = (unsigned char *)calloc((size_t)M, 1);
     return k;
@@ -168,7 +168,7 @@ static void work_free(work_t *k)
     free(k->w); free(k->lam); free(k->nuf); free(k->s); free(k->z); free(k->D); free(k->Phi); free(k->L);
     free(k->Kx); free(k->Pr); free(k->mb); free(k->rd); free(k->rdyn); free(k->rc); free(k->g); free(k->rhs_c);
     free(k->pvec); free(k->lu); free(k->w1); free(k->lam1); free(k->nuf1); free(k->z1); free(k->w2);
-    free(k->lam2); free(k->nuf2); free(k->z2); free(k->dsa); free(k->dza); free(k->Pw); free(k->sd); free(k->sc); free(k->act); free(k);
+    free(k->lam2); free(k->nuf2); free(k->z2); free(k->dsa); free(k->dza); free(k->Pw); free(k->sd); free(k->sc); free(k->ed); free(k->edyn); free(k->ec); free(k->act); free(k);
 }
 
 /* Riccati factorisation of  Phi_t = P + C_t' D C_t  along the horizon.
@@ -350,10 +350,59 @@ static void kkt_solve(const prob_t *p, work_t *k, const int8_t *fix, const doubl
     }
 }
 
+/* Residual of the linear blocks  K d = (rhs_d ; rhs_e ; rhs_c) + dtau (0 ; f ; h)  at a computed d.
+ * The prescribed components (x_0, fixed binaries) are met exactly by construction. */
+static void kkt_residual(const prob_t *p, const work_t *k, const int8_t *fix, const double *rhs_d, const double *cdyn,
+                         const double *rhs_c, double dtau, const double *dw, const double *dlam, const double *dnuf,
+                         const double *dz, double *ed, double *edyn, double *ec)
+{
+    int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub;
+    for (int t = 0; t < T; t++) {
+        const double *C = Ct(p, t); const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+        double *e = ed + t * nz;
+        for (int i = 0; i < nz; i++) {
+            double a = rhs_d[t * nz + i];
+            for (int j = 0; j < nz; j++) a -= p->P[i * nz + j] * dw[t * nz + j];
+            e[i] = a;
+        }
+        for (int j = 0; j < nx; j++) {
+            double a = dlam[t * nx + j];
+            for (int l = 0; l < nx; l++) a -= p->A[l * nx + j] * dlam[(t + 1) * nx + l];
+            e[j] -= a;
+        }
+        for (int j = 0; j < nu; j++) {
+            double a = 0;
+            for (int l = 0; l < nx; l++) a -= p->B[l * nu + j] * dlam[(t + 1) * nx + l];
+            e[nx + j] -= a;
+        }
+        for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) e[nx + nuc + b] -= dnuf[t * nub + b];
+        for (int r = 0; r < m; r++) {
+            if (!k->act[ro + r]) { ec[ro + r] = 0; continue; }
+            double a = rhs_c[ro + r] + dtau * hh[r] + dz[ro + r] * k->s[ro + r] / k->z[ro + r];
+            for (int j = 0; j < nz; j++) { double c = C[r * nz + j]; if (c != 0.0) { e[j] -= c * dz[ro + r]; a -= c * dw[t * nz + j]; } }
+            ec[ro + r] = a;
+        }
+        /* x_0 and fixed binaries are prescribed: their stationarity rows define dlam_0 / dnuf */
+        for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) e[nx + nuc + b] = 0;
+        for (int i = 0; i < nx; i++) {
+            double a = cdyn[t * nx + i] - dw[(t + 1) * nz + i];
+            for (int l = 0; l < nx; l++) a += p->A[i * nx + l] * dw[t * nz + l];
+            for (int l = 0; l < nu; l++) a += p->B[i * nu + l] * dw[t * nz + nx + l];
+            edyn[t * nx + i] = a;
+        }
+    }
+    for (int j = 0; j < nx; j++) {
+        double a = rhs_d[T * nz + j] - dlam[T * nx + j];
+        for (int l = 0; l < nx; l++) a -= p->PT[j * nx + l] * dw[T * nz + l];
+        ed[T * nz + j] = a;
+    }
+    for (int j = 0; j < nx; j++) ed[j] = 0;   /* x_0 row defines dlam_0 */
+}
+
 static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i < n; i++) if (fabs(v[i]) > m) m = fabs(v[i]); return m; }
 
 /* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
-static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, double tol, double tol_inf, int max_iter,
+static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, double tol, double tol_inf, int max_iter,
                      double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol)
 {
     int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
@@ -484,18 +533,32 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             }
             double dtau = (lin * rg - dkap_rhs / tau + g2 + fy2 + hz2) / den;
             double dkap = -(dkap_rhs + kap * dtau) / tau;
-            /* combine and step length */
+            /* combined direction d = v2 + dtau v1 (kept in the "2" arrays) */
+            for (int i = 0; i < n; i++) k->w2[i] += dtau * k->w1[i];
+            for (int i = 0; i < (T + 1) * nx; i++) k->lam2[i] += dtau * k->lam1[i];
+            for (int i = 0; i < T * nub; i++) k->nuf2[i] += dtau * k->nuf1[i];
+            for (int r = 0; r < M; r++) k->z2[r] = k->act[r] ? k->z2[r] + dtau * k->z1[r] : 0.0;
+            if (pass == 1 && refine) {
+                /* one step of iterative refinement against the three linear blocks of the
+                 * Newton system at this dtau:  K d = rhs2 + dtau rhs1                      */
+                kkt_residual(p, k, fix, sd, sc, k->rhs_c, dtau, k->w2, k->lam2, k->nuf2, k->z2, k->ed, k->edyn, k->ec);
+                kkt_solve(p, k, fix, k->ed, NULL, k->edyn, 0, k->ec, k->w1, k->lam1, k->nuf1, k->z1); /* v1 no longer needed */
+                for (int i = 0; i < n; i++) k->w2[i] += k->w1[i];
+                for (int i = 0; i < (T + 1) * nx; i++) k->lam2[i] += k->lam1[i];
+                for (int i = 0; i < T * nub; i++) k->nuf2[i] += k->nuf1[i];
+                for (int r = 0; r < M; r++) if (k->act[r]) k->z2[r] += k->z1[r];
+            }
+            /* slack step from the complementarity row, step length to the boundary */
             double amax = 1e30;
             if (dtau < 0) amax = fmin(amax, -tau / dtau);
             if (dkap < 0) amax = fmin(amax, -kap / dkap);
             for (int r = 0; r < M; r++) {
-                if (!k->act[r]) { k->z2[r] = 0; k->dsa[r] = 0; continue; }
-                double dz = k->z2[r] + dtau * k->z1[r];
+                if (!k->act[r]) { k->dsa[r] = 0; continue; }
+                double dz = k->z2[r];
                 double dsr = k->s[r] * k->z[r] + (pass ? k->dsa[r] * k->dza[r] - sigma * mu : 0.0);
                 double ds = -(dsr + k->s[r] * dz) / k->z[r];
                 if (dz < 0) amax = fmin(amax, -k->z[r] / dz);
                 if (ds < 0) amax = fmin(amax, -k->s[r] / ds);
-                k->z2[r] = dz;
                 if (pass == 0) { k->dza[r] = dz; k->dsa[r] = ds; } else k->rhs_c[r] = ds; /* rhs_c reused as ds */
             }
             if (pass == 0) {
@@ -505,9 +568,9 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             } else {
                 alpha = fmin(1.0, 0.99 * amax);
                 if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      sigma %.3e alpha %.3e dtau %.3e\n", sigma, alpha, dtau);
-                for (int i = 0; i < n; i++) k->w[i] += alpha * (k->w2[i] + dtau * k->w1[i]);
-                for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] += alpha * (k->lam2[i] + dtau * k->lam1[i]);
-                for (int i = 0; i < T * nub; i++) k->nuf[i] += alpha * (k->nuf2[i] + dtau * k->nuf1[i]);
+                for (int i = 0; i < n; i++) k->w[i] += alpha * k->w2[i];
+                for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] += alpha * k->lam2[i];
+                for (int i = 0; i < T * nub; i++) k->nuf[i] += alpha * k->nuf2[i];
                 for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] += alpha * k->z2[r]; k->s[r] += alpha * k->rhs_c[r]; }
                 tau += alpha * dtau; kap += alpha * dkap;
                 for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
@@ -590,7 +653,7 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
                        const double *FL, const double *GL, const double *hL,
                        const double *Q, const double *R, const double *QT,
                        const double *x0, int x0_stride, int nbatch, const int8_t *fix,
-                       double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal,
+                       double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal, int refine,
                        double *obj, double *dobj, int *status, int *iters, double *primal, double *dual)
 {
     if (nx + nu > 64 || nx > 32) return -1;
@@ -613,10 +676,10 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
             const double *xb = x0 + (size_t)b * x0_stride; const int8_t *fb = fix + (size_t)b * T * nub;
             double *pb = primal + (size_t)b * np_, *db = dual + (size_t)b * nd, tv = 0; int it1 = 0, it2 = 0, st;
             if (ncL > nc && lazy_terminal) {
-                st = solve_one(p, k, xb, fb, 0, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
+                st = solve_one(p, k, xb, fb, 0, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
                 if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)))
-                    st = solve_one(p, k, xb, fb, 1, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv);
-            } else st = solve_one(p, k, xb, fb, 1, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
+                    st = solve_one(p, k, xb, fb, 1, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv);
+            } else st = solve_one(p, k, xb, fb, 1, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
             status[b] = st; iters[b] = it1 + it2;
         }
         work_free(k);
