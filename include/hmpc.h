@@ -1,0 +1,131 @@
+/*
+ * hmpc.h -- C ABI of the MI355X batched QP-relaxation solver for hybrid MPC.
+ *
+ * This is the drop-in boundary for ONE hot path of TobiaMarcucci/warm-start-hybrid-mpc:
+ * the QP relaxation solved at every branch-and-bound node.  In the reference that path is
+ *
+ *   warm_start_hmpc/controller.py:365-376   solver(identifier, cutoff, extra) closure
+ *   warm_start_hmpc/controller.py:229-271   _solve_subproblem  (set bounds, set x0, optimize)
+ *   warm_start_hmpc/controller.py:273-298   _set_bound_binaries
+ *   warm_start_hmpc/bounded_qp.py:200-228   BoundedQP.optimize (+ Farkas proof if infeasible)
+ *   warm_start_hmpc/subproblem_solution.py:18-168  extraction of the primal/dual record
+ *
+ * and it bottoms out in Gurobi's C library through gurobipy.  The entry points below are
+ * what a binding for that path needs: build the node-independent QP once (the role of
+ * controller.py:119-184 _build_mip), then solve any number of nodes -- each given by its
+ * vector of binary fixings and an initial state -- in one call.  Plain pointers and sizes
+ * only; all matrices row-major float64.
+ *
+ * The QP of one node (reference statement: controller.py:47-56, 119-184):
+ *
+ *   min  sum_{t<T} |Q x_t|^2 + |R u_t|^2  +  |Q_T x_T|^2
+ *   s.t. x_0 = x0                                  (multiplier lam_0)
+ *        x_{t+1} = A x_t + B u_t                   (lam_{t+1})
+ *        F x_t + G u_t <= h            t < T-1     (mu_t >= 0)
+ *        F_Tm1 x_t + G_Tm1 u_t <= h_Tm1  t = T-1   (mu_{T-1} >= 0)
+ *        lb_t <= ub_t <= ubmax_t                   (nu_lb_t, nu_ub_t >= 0)
+ *
+ * with u_t = (uc_t, ub_t), ub_t the last nub entries, and (lb, ubmax) = (0, 1) for a free
+ * binary, (v, v) for a binary fixed to v.  Sign conventions are the reference's
+ * (bounded_qp.py:260-332): inequality multipliers are nonnegative; an infeasible node has
+ * objective +inf, no primal, and multipliers that form a Farkas proof whose "dual
+ * objective" -sum(rhs * multiplier) is positive.
+ */
+#ifndef HMPC_H
+#define HMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-node status (hmpc_result.status) */
+#define HMPC_OPTIMAL 0
+#define HMPC_INFEASIBLE 1
+#define HMPC_MAXITER 2   /* not converged: the caller must not use the record */
+#define HMPC_NUMERICAL 3 /* numerical breakdown: idem */
+
+/* return codes */
+#define HMPC_OK 0
+#define HMPC_EINVAL -1 /* bad argument (sizes, null pointers) */
+#define HMPC_EDEVICE -2 /* HIP error; text in hmpc_last_error() */
+#define HMPC_ETOOBIG -3 /* problem does not fit the LDS-resident kernel */
+
+/* Node-independent problem data (replaces the Gurobi model built by controller.py:119-184).
+ * nc  = rows of [F G];  ncT = rows of [F_Tm1 G_Tm1] (= nc + terminal facets, controller.py:85-87).
+ * nq, nr, nqT = rows of Q, R, Q_T. */
+typedef struct hmpc_problem {
+    int32_t nx, nu, nub, T, nc, ncT, nq, nr, nqT;
+    const double *A;     /* nx  x nx */
+    const double *B;     /* nx  x nu */
+    const double *F;     /* nc  x nx */
+    const double *G;     /* nc  x nu */
+    const double *h;     /* nc       */
+    const double *F_Tm1; /* ncT x nx */
+    const double *G_Tm1; /* ncT x nu */
+    const double *h_Tm1; /* ncT      */
+    const double *Q;     /* nq  x nx */
+    const double *R;     /* nr  x nu */
+    const double *Q_T;   /* nqT x nx */
+} hmpc_problem;
+
+/* Solver options (the role of the reference's gurobi_params, controller.py:778-796). */
+typedef struct hmpc_options {
+    double tol;            /* optimality: scaled residuals and relative gap (default 1e-8)   */
+    double tol_inf;        /* infeasibility proof: |A'y| <= tol_inf * (-b'y) (default 1e-6) */
+    int32_t max_iter;      /* interior-point iterations per solve (default 100)             */
+    int32_t lazy_terminal; /* 1: try each node without the terminal-set rows first          */
+    int32_t refine;        /* 1: one step of iterative refinement per Newton direction      */
+    int32_t device;        /* HIP device ordinal, -1 = current                              */
+} hmpc_options;
+
+/* Structure-of-arrays result of a batch of B nodes.  Any pointer may be NULL (not wanted).
+ * primal row (n_primal doubles): x_0..x_T (nx each), then u_0..u_{T-1} (nu each; uc then ub).
+ *   NaN for an infeasible node.
+ * dual row (n_dual doubles), in this order (subproblem_solution.py:142-166):
+ *   lam_0..lam_T (nx) | mu_0..mu_{T-2} (nc), mu_{T-1} (ncT) | nu_lb_0.. (nub) | nu_ub_0.. (nub)
+ *   | rho_0..rho_{T-1} (nq), rho_T (nqT) | sigma_0..sigma_{T-1} (nr)
+ *   with rho_t = 2 Q x_t, rho_T = 2 Q_T x_T, sigma_t = 2 R u_t, zeros for an infeasible node. */
+typedef struct hmpc_result {
+    double *obj;      /* B : primal objective, +inf if infeasible (bounded_qp.py:292-311)      */
+    double *dual_obj; /* B : dual objective / Farkas objective   (bounded_qp.py:313-332)      */
+    int32_t *status;  /* B                                                                    */
+    int32_t *iters;   /* B : interior-point iterations spent on the node                      */
+    double *primal;   /* B x n_primal                                                         */
+    double *dual;     /* B x n_dual                                                           */
+} hmpc_result;
+
+typedef struct hmpc_handle hmpc_handle;
+
+/* Copies the problem to the device, precomputes scalings and sparse row/column lists.
+ * options may be NULL (defaults).  The handle is bound to one device and is not thread-safe. */
+int hmpc_create(const hmpc_problem *problem, const hmpc_options *options, hmpc_handle **out);
+int hmpc_destroy(hmpc_handle *h);
+
+/* Row lengths of hmpc_result.primal / .dual for this problem. */
+int hmpc_record_sizes(const hmpc_handle *h, int32_t *n_primal, int32_t *n_dual);
+
+/* Solves B nodes.  fix: B x (T*nub) int8, entry (t*nub+i) = -1 free, 0 or 1 fixed
+ * (the identifier dictionaries of controller.py:273-298 flattened).  x0: nx doubles shared by
+ * all nodes when x0_stride == 0, else B rows of stride x0_stride.
+ * Host-pointer form: copies in, runs, copies out, returns when done.  Replaces
+ * B calls of controller.py:229-271. */
+int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_stride, const int8_t *fix, int32_t B,
+                     const hmpc_result *out);
+
+/* Device-pointer form: every pointer (x0, fix, and the members of out) is device memory on the
+ * handle's device; the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream). */
+int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B,
+                            const hmpc_result *d_out, void *stream);
+
+/* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
+int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);
+
+/* Text of the last error on this thread ("" if none). */
+const char *hmpc_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HMPC_H */

@@ -1,0 +1,364 @@
+// hmpc_capi.hip -- host side of the C ABI declared in include/hmpc.h.
+//
+// hmpc_create   : scales the stage constraints, builds the sparse row / column / Gram lists the
+//                 kernel walks, uploads everything once (the role of controller.py:119-184, which
+//                 builds the Gurobi model once per controller).
+// hmpc_solve_*  : one kernel launch per batch of nodes (replaces B sequential calls of
+//                 controller.py:229-271 + bounded_qp.py:200-228).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hmpc_device.h"
+
+extern "C" __global__ void hmpc_qp_kernel(const DevProb p, const double *x0g, int x0_stride, const int8_t *fixg, int B,
+                                          const DevOut out, double *rows_ws, double *trace);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(HMPC_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+struct hmpc_handle {
+    int device = 0;
+    DevProb dp{};
+    std::vector<void *> allocs;
+    double *rows_ws = nullptr;
+    double *trace = nullptr;
+    size_t lds = 0;
+    int max_grid = 0, last_grid = 0;
+    // staging for the host-pointer entry point
+    void *d_x0 = nullptr, *d_fix = nullptr, *d_obj = nullptr, *d_dobj = nullptr, *d_status = nullptr,
+         *d_iters = nullptr, *d_primal = nullptr, *d_dual = nullptr;
+    int staged = 0;
+};
+
+namespace {
+
+struct StageHost {
+    int m, mg;
+    std::vector<double> C, h, scale; // dense m x nz, scaled
+    std::vector<int> rptr, rcol, cptr, crow, gptr, grow;
+    std::vector<double> rval, cval, gval;
+};
+
+// [F G] rows scaled to unit norm, then the bound rows of the binaries.
+void build_stage(const hmpc_problem &q, const double *F, const double *G, const double *h, int nrow, StageHost &s)
+{
+    const int nx = q.nx, nu = q.nu, nz = nx + nu, nub = q.nub, nuc = nu - nub;
+    s.mg = nrow;
+    s.m = nrow + 2 * nub;
+    s.C.assign((size_t)s.m * nz, 0.0);
+    s.h.assign(s.m, 0.0);
+    s.scale.assign(nrow > 0 ? nrow : 1, 1.0);
+    for (int r = 0; r < nrow; r++) {
+        double n2 = 0;
+        for (int j = 0; j < nx; j++) n2 += F[r * nx + j] * F[r * nx + j];
+        for (int j = 0; j < nu; j++) n2 += G[r * nu + j] * G[r * nu + j];
+        const double sc = n2 > 0 ? 1.0 / std::sqrt(n2) : 1.0;
+        s.scale[r] = sc;
+        for (int j = 0; j < nx; j++) s.C[(size_t)r * nz + j] = sc * F[r * nx + j];
+        for (int j = 0; j < nu; j++) s.C[(size_t)r * nz + nx + j] = sc * G[r * nu + j];
+        s.h[r] = sc * h[r];
+    }
+    for (int i = 0; i < nub; i++) {
+        s.C[(size_t)(nrow + i) * nz + nx + nuc + i] = -1.0; // -ub <= 0
+        s.C[(size_t)(nrow + nub + i) * nz + nx + nuc + i] = 1.0; // ub <= 1
+        s.h[nrow + nub + i] = 1.0;
+    }
+    // rows
+    s.rptr.assign(1, 0);
+    for (int r = 0; r < s.m; r++) {
+        for (int j = 0; j < nz; j++)
+            if (s.C[(size_t)r * nz + j] != 0.0) { s.rcol.push_back(j); s.rval.push_back(s.C[(size_t)r * nz + j]); }
+        s.rptr.push_back((int)s.rcol.size());
+    }
+    // columns
+    s.cptr.assign(1, 0);
+    for (int j = 0; j < nz; j++) {
+        for (int r = 0; r < s.m; r++)
+            if (s.C[(size_t)r * nz + j] != 0.0) { s.crow.push_back(r); s.cval.push_back(s.C[(size_t)r * nz + j]); }
+        s.cptr.push_back((int)s.crow.size());
+    }
+    // Gram lists over the lower triangle, entry e = i (i + 1) / 2 + j
+    s.gptr.assign(1, 0);
+    for (int i = 0; i < nz; i++)
+        for (int j = 0; j <= i; j++) {
+            for (int r = 0; r < s.m; r++) {
+                const double v = s.C[(size_t)r * nz + i] * s.C[(size_t)r * nz + j];
+                if (v != 0.0) { s.grow.push_back(r); s.gval.push_back(v); }
+            }
+            s.gptr.push_back((int)s.grow.size());
+        }
+}
+
+template <class T>
+int upload(hmpc_handle *h, const std::vector<T> &v, const T **out)
+{
+    void *d = nullptr;
+    const size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
+    HIPCHK(hipMalloc(&d, bytes));
+    h->allocs.push_back(d);
+    if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T *>(d);
+    return HMPC_OK;
+}
+
+int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
+{
+    d.m = s.m;
+    d.mg = s.mg;
+    int rc;
+    if ((rc = upload(h, s.rptr, &d.rptr))) return rc;
+    if ((rc = upload(h, s.rcol, &d.rcol))) return rc;
+    if ((rc = upload(h, s.rval, &d.rval))) return rc;
+    if ((rc = upload(h, s.cptr, &d.cptr))) return rc;
+    if ((rc = upload(h, s.crow, &d.crow))) return rc;
+    if ((rc = upload(h, s.cval, &d.cval))) return rc;
+    if ((rc = upload(h, s.gptr, &d.gptr))) return rc;
+    if ((rc = upload(h, s.grow, &d.grow))) return rc;
+    if ((rc = upload(h, s.gval, &d.gval))) return rc;
+    if ((rc = upload(h, s.h, &d.h))) return rc;
+    if ((rc = upload(h, s.scale, &d.scale))) return rc;
+    return HMPC_OK;
+}
+
+} // namespace
+
+extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out)
+{
+    g_err.clear();
+    if (!q || !out) return fail(HMPC_EINVAL, "null problem or output pointer");
+    if (q->nx < 1 || q->nu < 1 || q->nub < 0 || q->nub > q->nu || q->T < 2 || q->nc < 0 || q->ncT < q->nc ||
+        q->nq < 0 || q->nr < 0 || q->nqT < 0)
+        return fail(HMPC_EINVAL, "inconsistent sizes (need nx,nu >= 1, 0 <= nub <= nu, T >= 2, ncT >= nc)");
+    if (!q->A || !q->B || !q->F || !q->G || !q->h || !q->F_Tm1 || !q->G_Tm1 || !q->h_Tm1 || !q->Q || !q->R || !q->Q_T)
+        return fail(HMPC_EINVAL, "null matrix pointer");
+
+    hmpc_handle *h = new hmpc_handle();
+    int dev = opt ? opt->device : -1;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "no HIP device available"); }
+    }
+    h->device = dev;
+    if (hipSetDevice(dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "hipSetDevice failed"); }
+
+    DevProb &p = h->dp;
+    p.nx = q->nx; p.nu = q->nu; p.nub = q->nub; p.nuc = q->nu - q->nub; p.nz = q->nx + q->nu; p.T = q->T;
+    p.nc = q->nc; p.ncL = q->ncT; p.mreg = q->nc + 2 * q->nub; p.mlast = q->ncT + 2 * q->nub;
+    p.M = (q->T - 1) * p.mreg + p.mlast; p.Mpad = (p.M + 63) / 64 * 64;
+    p.n = q->T * p.nz + q->nx; p.ne = p.nz * (p.nz + 1) / 2;
+    p.nq = q->nq; p.nr = q->nr; p.nqT = q->nqT;
+    p.n_primal = (q->T + 1) * q->nx + q->T * q->nu;
+    p.n_dual = (q->T + 1) * q->nx + (q->T - 1) * q->nc + q->ncT + 2 * q->T * q->nub + q->T * q->nq + q->nqT + q->T * q->nr;
+    p.tol = opt && opt->tol > 0 ? opt->tol : 1e-8;
+    p.tol_inf = opt && opt->tol_inf > 0 ? opt->tol_inf : 1e-6;
+    p.max_iter = opt && opt->max_iter > 0 ? opt->max_iter : 100;
+    p.lazy = opt ? opt->lazy_terminal : 1;
+    p.refine = opt ? opt->refine : 1;
+
+    const int nx = p.nx, nu = p.nu, nz = p.nz;
+    StageHost reg, last;
+    build_stage(*q, q->F, q->G, q->h, q->nc, reg);
+    build_stage(*q, q->F_Tm1, q->G_Tm1, q->h_Tm1, q->ncT, last);
+
+    // cost Hessians, scaled so that their largest entry is one
+    std::vector<double> P((size_t)nz * nz, 0.0), PT((size_t)nx * nx, 0.0);
+    double big = 0;
+    for (int i = 0; i < nx; i++)
+        for (int j = 0; j < nx; j++) {
+            double a = 0, b = 0;
+            for (int k = 0; k < q->nq; k++) a += q->Q[k * nx + i] * q->Q[k * nx + j];
+            for (int k = 0; k < q->nqT; k++) b += q->Q_T[k * nx + i] * q->Q_T[k * nx + j];
+            P[(size_t)i * nz + j] = 2 * a;
+            PT[(size_t)i * nx + j] = 2 * b;
+            big = std::fmax(big, std::fmax(std::fabs(2 * a), std::fabs(2 * b)));
+        }
+    for (int i = 0; i < nu; i++)
+        for (int j = 0; j < nu; j++) {
+            double a = 0;
+            for (int k = 0; k < q->nr; k++) a += q->R[k * nu + i] * q->R[k * nu + j];
+            P[(size_t)(nx + i) * nz + nx + j] = 2 * a;
+            big = std::fmax(big, std::fabs(2 * a));
+        }
+    p.cs = big > 0 ? 1.0 / big : 1.0;
+    for (auto &v : P) v *= p.cs;
+    for (auto &v : PT) v *= p.cs;
+
+    std::vector<int> ei, ej;
+    for (int i = 0; i < nz; i++)
+        for (int j = 0; j <= i; j++) { ei.push_back(i); ej.push_back(j); }
+
+    auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
+    int rc = HMPC_OK;
+    do {
+        if ((rc = upload_stage(h, reg, p.st[0]))) break;
+        if ((rc = upload_stage(h, last, p.st[1]))) break;
+        if ((rc = upload(h, vec(q->A, (size_t)nx * nx), &p.A))) break;
+        if ((rc = upload(h, vec(q->B, (size_t)nx * nu), &p.B))) break;
+        if ((rc = upload(h, P, &p.P))) break;
+        if ((rc = upload(h, PT, &p.PT))) break;
+        if ((rc = upload(h, vec(q->Q, (size_t)q->nq * nx), &p.Q))) break;
+        if ((rc = upload(h, vec(q->R, (size_t)q->nr * nu), &p.R))) break;
+        if ((rc = upload(h, vec(q->Q_T, (size_t)q->nqT * nx), &p.QT))) break;
+        if ((rc = upload(h, ei, &p.ei))) break;
+        if ((rc = upload(h, ej, &p.ej))) break;
+    } while (0);
+    if (rc) { hmpc_destroy(h); return rc; }
+
+    // launch geometry: one 64-lane workgroup per node in flight, as many per CU as LDS admits
+    h->lds = hmpc_lds_bytes(p);
+    int cus = 0, lds_max = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    const size_t lds_cu = 160 * 1024;
+    if (h->lds > lds_cu || (lds_max > 0 && h->lds > (size_t)lds_max)) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", h->lds, lds_max);
+        hmpc_destroy(h);
+        return fail(HMPC_ETOOBIG, msg);
+    }
+    if (hipFuncSetAttribute((const void *)hmpc_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+        hmpc_destroy(h);
+        return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
+    }
+    int per_cu = (int)(lds_cu / h->lds);
+    if (per_cu > 8) per_cu = 8;
+    const char *env = getenv("HMPC_BLOCKS_PER_CU");
+    if (env && atoi(env) > 0) per_cu = atoi(env);
+    h->max_grid = (cus > 0 ? cus : 256) * per_cu;
+    if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 5 * p.Mpad * sizeof(double)) != hipSuccess) {
+        hmpc_destroy(h);
+        return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
+    }
+    if (getenv("HMPC_TRACE")) {
+        (void)hipMalloc((void **)&h->trace, 2 * 64 * 8 * sizeof(double));
+        (void)hipMemset(h->trace, 0, 2 * 64 * 8 * sizeof(double));
+    }
+    *out = h;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_destroy(hmpc_handle *h)
+{
+    if (!h) return HMPC_OK;
+    (void)hipSetDevice(h->device);
+    for (void *d : h->allocs) (void)hipFree(d);
+    if (h->rows_ws) (void)hipFree(h->rows_ws);
+    if (h->trace) (void)hipFree(h->trace);
+    for (void *d : {h->d_x0, h->d_fix, h->d_obj, h->d_dobj, h->d_status, h->d_iters, h->d_primal, h->d_dual})
+        if (d) (void)hipFree(d);
+    delete h;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_record_sizes(const hmpc_handle *h, int32_t *n_primal, int32_t *n_dual)
+{
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    if (n_primal) *n_primal = h->dp.n_primal;
+    if (n_dual) *n_dual = h->dp.n_dual;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes)
+{
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    if (grid) *grid = h->last_grid;
+    if (lds_bytes) *lds_bytes = (int32_t)h->lds;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix,
+                                       int32_t B, const hmpc_result *d_out, void *stream)
+{
+    g_err.clear();
+    if (!h || !d_x0 || !d_fix || !d_out) return fail(HMPC_EINVAL, "null argument");
+    if (B < 0 || (x0_stride != 0 && x0_stride < h->dp.nx)) return fail(HMPC_EINVAL, "bad batch size or x0 stride");
+    if (B == 0) return HMPC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
+    const int grid = B < h->max_grid ? B : h->max_grid;
+    h->last_grid = grid;
+    hipLaunchKernelGGL(hmpc_qp_kernel, dim3(grid), dim3(64), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride, d_fix,
+                       B, o, h->rows_ws, h->trace);
+    HIPCHK(hipGetLastError());
+    return HMPC_OK;
+}
+
+static int ensure_staging(hmpc_handle *h, int B)
+{
+    if (B <= h->staged) return HMPC_OK;
+    for (void **d : {&h->d_x0, &h->d_fix, &h->d_obj, &h->d_dobj, &h->d_status, &h->d_iters, &h->d_primal, &h->d_dual})
+        if (*d) { (void)hipFree(*d); *d = nullptr; }
+    h->staged = 0;
+    const DevProb &p = h->dp;
+    HIPCHK(hipMalloc(&h->d_x0, (size_t)B * p.nx * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_fix, (size_t)B * p.T * p.nub + 1));
+    HIPCHK(hipMalloc(&h->d_obj, (size_t)B * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_dobj, (size_t)B * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_status, (size_t)B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_iters, (size_t)B * sizeof(int32_t)));
+    HIPCHK(hipMalloc(&h->d_primal, (size_t)B * p.n_primal * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_dual, (size_t)B * p.n_dual * sizeof(double)));
+    h->staged = B;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_stride, const int8_t *fix, int32_t B,
+                                const hmpc_result *out)
+{
+    g_err.clear();
+    if (!h || !x0 || !fix || !out) return fail(HMPC_EINVAL, "null argument");
+    if (B < 0 || (x0_stride != 0 && x0_stride < h->dp.nx)) return fail(HMPC_EINVAL, "bad batch size or x0 stride");
+    if (B == 0) return HMPC_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const DevProb &p = h->dp;
+    int rc = ensure_staging(h, B);
+    if (rc) return rc;
+    if (x0_stride == 0) {
+        HIPCHK(hipMemcpy(h->d_x0, x0, p.nx * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMemcpy2D(h->d_x0, p.nx * sizeof(double), x0, x0_stride * sizeof(double), p.nx * sizeof(double), B,
+                           hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(h->d_fix, fix, (size_t)B * p.T * p.nub, hipMemcpyHostToDevice));
+    hmpc_result d{(double *)h->d_obj, (double *)h->d_dobj, (int32_t *)h->d_status, (int32_t *)h->d_iters,
+                  out->primal ? (double *)h->d_primal : nullptr, out->dual ? (double *)h->d_dual : nullptr};
+    rc = hmpc_solve_batch_device(h, (const double *)h->d_x0, x0_stride == 0 ? 0 : p.nx, (const int8_t *)h->d_fix, B, &d, nullptr);
+    if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (out->obj) HIPCHK(hipMemcpy(out->obj, h->d_obj, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->dual_obj) HIPCHK(hipMemcpy(out->dual_obj, h->d_dobj, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->status) HIPCHK(hipMemcpy(out->status, h->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out->iters) HIPCHK(hipMemcpy(out->iters, h->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (out->primal) HIPCHK(hipMemcpy(out->primal, h->d_primal, (size_t)B * p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->dual) HIPCHK(hipMemcpy(out->dual, h->d_dual, (size_t)B * p.n_dual * sizeof(double), hipMemcpyDeviceToHost));
+    if (h->trace) {
+        std::vector<double> tr(2 * 64 * 8);
+        (void)hipMemcpy(tr.data(), h->trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost);
+        for (int ph = 0; ph < 2; ph++)
+            for (int it = 0; it < 64; it++) {
+                const double *t = &tr[(ph * 64 + it) * 8];
+                if (t[0] == 0.0) break;
+                fprintf(stderr, "hip ph %d it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e eta %.3e cert %.3e\n", ph, it,
+                        t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
+            }
+        (void)hipMemset(h->trace, 0, tr.size() * sizeof(double));
+    }
+    return HMPC_OK;
+}

@@ -1,0 +1,56 @@
+// hmpc_device.h -- structures shared by the host side of the C ABI and the kernel.
+#ifndef HMPC_DEVICE_H
+#define HMPC_DEVICE_H
+
+#include <stdint.h>
+
+#include "hmpc.h"
+
+// Constraint rows of one stage type (0: stages 0..T-2, 1: stage T-1 with the terminal set),
+// bound rows of the binaries appended ([F G] rows, then -ub <= -lb, then ub <= ubmax),
+// general rows scaled to unit 2-norm.  All arrays are device pointers.
+struct SparseStage {
+    int m, mg;                 // rows with / without the bound rows
+    const int *rptr, *rcol;    // rows (CSR):    C w        row-parallel
+    const double *rval;
+    const int *cptr, *crow;    // columns (CSC): C' v       entry-parallel
+    const double *cval;
+    const int *gptr, *grow;    // Gram lists:    (C' D C)(i,j) = sum_k gval[k] D[grow[k]], i >= j
+    const double *gval;
+    const double *h;           // m scaled right-hand sides
+    const double *scale;       // mg row scales
+};
+
+struct DevProb {
+    int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, Mpad, n, ne, nq, nr, nqT, n_primal, n_dual;
+    SparseStage st[2];
+    const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
+    const int *ei, *ej;                        // lower-triangle entry -> (i, j)
+    double cs;                                 // cost scale
+    double tol, tol_inf;
+    int max_iter, lazy, refine;
+};
+
+struct DevOut {
+    double *obj, *dual_obj;
+    int32_t *status, *iters;
+    double *primal, *dual;
+};
+
+// LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).
+static inline size_t hmpc_lds_bytes(const DevProb &p)
+{
+    const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
+    size_t d = 0;
+    d += n + (T + 1) * nx + T * nub;                                   // w lam nuf
+    d += 3 * M;                                                        // z D e
+    d += T * nu * nu + T * nu * nx + (T + 1) * nx * nx + T * nz + T * nu; // Minv Kg Pr mb mus
+    d += n + T * nx + n + n + (T + 1) * nx;                            // rd rdyn Pw g pv
+    d += 2 * (n + (T + 1) * nx + T * nub);                             // w1.. w2..
+    d += n + T * nx;                                                   // ed edyn
+    d += nz * nz + nz * nu + nx * nz + nx + nz;                        // Mm E PA q mv
+    d += nx;                                                           // x0
+    return d * sizeof(double) + T * nub * sizeof(int);
+}
+
+#endif

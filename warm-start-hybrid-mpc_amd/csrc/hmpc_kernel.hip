@@ -1,0 +1,750 @@
+// hmpc_kernel.hip -- batched QP relaxations of hybrid-MPC branch-and-bound nodes on gfx950.
+//
+// One wavefront (64 lanes) owns one node's QP from start to finish:
+//   * the node-independent problem (A, B, cost Hessians, sparse row / column / Gram lists of the
+//     stage constraints) is read-only global data shared by every wave (L1/L2 resident, ~20 KB);
+//   * everything indexed by stage -- iterate, Newton directions, Riccati factor (gain, inverse
+//     input Hessian, cost-to-go per stage) -- and the three per-row vectors that other lanes must
+//     see (multipliers z, barrier weights D = z/s, scaled right-hand side e) live in LDS;
+//   * per-row temporaries that only their own lane touches (slack s, row residual, the constant
+//     direction, affine products) live in a per-workgroup slab of global memory, written and read
+//     coalesced (row r <-> lane r % 64), small enough to stay in L2 / Infinity Cache;
+//   * reductions (complementarity, residual norms, step length) are wave shuffles -- no atomics,
+//     so a node's result does not depend on the batch it is solved in.
+//
+// Algorithm (same as the CPU oracle, oracle/hsde_qp.c): Mehrotra predictor-corrector on the
+// homogeneous embedding of the QP; each KKT solve is a Riccati sweep over the horizon with fixed
+// binaries handled as prescribed variables; one step of iterative refinement on the final
+// direction; terminal-set rows are tried masked first ("lazy terminal set").
+//
+// The reference (warm_start_hmpc/controller.py:229-271 -> bounded_qp.py:200-228) solves these QPs
+// one at a time inside Gurobi; conventions of the output record follow
+// warm_start_hmpc/subproblem_solution.py:68-168 and bounded_qp.py:260-332.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "hmpc_device.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+struct Lds {
+    double *w, *lam, *nuf, *z, *D, *e;
+    double *Minv, *Kg, *Pr, *mb, *mus;
+    double *rd, *rdyn, *Pw, *g, *pv;
+    double *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
+    double *ed, *edyn;
+    double *Mm, *E, *PA, *q, *mv;
+    double *x0;
+    int *fix;
+};
+
+struct Rows { // per-workgroup slab in global memory, row r <-> lane r % 64
+    double *s, *rc, *z1, *dz, *prod;
+};
+
+__device__ __forceinline__ void row_decode(const DevProb &p, int r, int &t, int &lr)
+{
+    t = r / p.mreg;
+    if (t > p.T - 1) t = p.T - 1;
+    lr = r - t * p.mreg;
+}
+
+__device__ __forceinline__ bool row_active(const DevProb &p, const int *fix, int t, int lr, int term_on)
+{
+    const int mg = (t < p.T - 1) ? p.nc : p.ncL;
+    if (lr < mg) return term_on || t < p.T - 1 || lr < p.nc;
+    int b = lr - mg;
+    if (b >= p.nub) b -= p.nub;
+    return fix[t * p.nub + b] < 0;
+}
+
+__device__ __forceinline__ double AB(const DevProb &p, int l, int j)
+{ // [A B](l, j)
+    return j < p.nx ? p.A[l * p.nx + j] : p.B[l * p.nu + (j - p.nx)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Riccati factorisation of Phi_t = P + C_t' D C_t.  Per stage it leaves in LDS
+//   Kg   = M_uu^{-1} M_ux        (nu x nx, feedback gain)
+//   Minv = M_uu^{-1}             (nu x nu)
+//   Pr_t = Schur complement      (nx x nx, cost-to-go Hessian)
+//   mb   = sum of the columns of M that belong to binaries fixed to one
+// with M = Phi_t + [A B]' Pr_{t+1} [A B] and the rows / columns of fixed binaries replaced by
+// identity (they are prescribed, not optimised).  Elimination runs on the symmetric matrix in
+// (u, x) order, one rank-one update per input and one barrier per update; carrying an identity
+// block through the same row operations yields the inverse and the gain without substitutions.
+// ---------------------------------------------------------------------------------------------
+__device__ int factor(const DevProb &p, const Lds &S, int lane)
+{
+    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub;
+    for (int i = lane; i < nx * nx; i += WAVE) S.Pr[T * nx * nx + i] = p.PT[i];
+    __syncthreads();
+    int bad = 0;
+    for (int t = T - 1; t >= 0; t--) {
+        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+        const double *Dt = S.D + t * p.mreg;
+        const double *Pn = S.Pr + (t + 1) * nx * nx;
+        // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
+        for (int e = lane; e < p.ne; e += WAVE) {
+            const int i = p.ei[e], j = p.ej[e];
+            double a = p.P[i * nz + j];
+            for (int k = st.gptr[e]; k < st.gptr[e + 1]; k++) a += st.gval[k] * Dt[st.grow[k]];
+            S.Mm[i * nz + j] = a;
+            S.Mm[j * nz + i] = a;
+        }
+        for (int e = lane; e < nx * nz; e += WAVE) {
+            const int i = e / nz, j = e - i * nz;
+            double a = 0;
+            for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * AB(p, l, j);
+            S.PA[e] = a;
+        }
+        __syncthreads();
+        for (int e = lane; e < p.ne; e += WAVE) {
+            const int i = p.ei[e], j = p.ej[e];
+            double a = 0;
+            for (int l = 0; l < nx; l++) a += AB(p, l, i) * S.PA[l * nz + j];
+            a += S.Mm[i * nz + j];
+            S.Mm[i * nz + j] = a;
+            S.Mm[j * nz + i] = a;
+        }
+        __syncthreads();
+        // columns of binaries fixed to one (needed by the constant direction)
+        for (int i = lane; i < nz; i += WAVE) {
+            double a = 0;
+            for (int b = 0; b < nub; b++)
+                if (S.fix[t * nub + b] == 1) a += S.Mm[i * nz + nx + nuc + b];
+            S.mb[t * nz + i] = a;
+        }
+        __syncthreads();
+        // prescribed inputs: identity row / column ; E = identity block on the inputs
+        for (int e = lane; e < nz * nz; e += WAVE) {
+            const int i = e / nz, j = e - i * nz;
+            const bool fi = i >= nx + nuc && S.fix[t * nub + (i - nx - nuc)] >= 0;
+            const bool fj = j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0;
+            if (fi || fj) S.Mm[e] = (i == j) ? 1.0 : 0.0;
+        }
+        for (int e = lane; e < nz * nu; e += WAVE) {
+            const int i = e / nu, c = e - i * nu;
+            S.E[e] = (i == nx + c) ? 1.0 : 0.0;
+        }
+        __syncthreads();
+        // elimination of the inputs, pivot order u_0 .. u_{nu-1}
+        for (int j = 0; j < nu; j++) {
+            const int pj = nx + j;
+            const double d = S.Mm[pj * nz + pj];
+            if (!(d > 0.0)) bad = 1;
+            const double rinv = 1.0 / d;
+            // rows still to be reduced: inputs j+1.. and all states.  Each lane owns one
+            // (row, column) pair of the trailing block or of the carried identity block.
+            const int nrem = nx + (nu - 1 - j);            // rows: states first, then later inputs
+            const int ncols = nrem + nu;                   // trailing columns + E columns
+            // In place: an entry is read and written by its own lane only; the pivot row and
+            // column, which every lane reads, are not part of the trailing block.
+            for (int e = lane; e < nrem * ncols; e += WAVE) {
+                const int a = e / ncols, bcol = e - a * ncols;
+                const int i = a < nx ? a : pj + 1 + (a - nx);
+                const double mij = S.Mm[i * nz + pj] * rinv;
+                if (bcol < nrem) {
+                    const int k = bcol < nx ? bcol : pj + 1 + (bcol - nx);
+                    S.Mm[i * nz + k] -= mij * S.Mm[pj * nz + k];
+                } else {
+                    const int c = bcol - nrem;
+                    S.E[i * nu + c] -= mij * S.E[pj * nu + c];
+                }
+            }
+            __syncthreads();
+        }
+        // After the sweep: Mm[x][x] = Schur complement, E[x][:] = -M_xu M_uu^{-1} = -Kg',
+        // E[u][:] = unit-lower inverse factor, pivots on the diagonal of Mm[u][u].
+        for (int e = lane; e < nx * nx; e += WAVE) {
+            const int i = e / nx, j = e - i * nx;
+            S.Pr[t * nx * nx + e] = S.Mm[i * nz + j];
+        }
+        for (int e = lane; e < nu * nx; e += WAVE) {
+            const int i = e / nx, c = e - i * nx;
+            S.Kg[t * nu * nx + e] = -S.E[c * nu + i];
+        }
+        for (int e = lane; e < nu * nu; e += WAVE) {
+            const int i = e / nu, j = e - i * nu;
+            double a = 0;
+            for (int l = (i > j ? i : j); l < nu; l++)
+                a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] / S.Mm[(nx + l) * nz + nx + l];
+            S.Minv[t * nu * nu + e] = a;
+        }
+        __syncthreads();
+    }
+    return __any(bad) ? -1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One KKT solve  K d = rhs  by a backward / forward Riccati sweep.
+//   rhs_d  : gs * gsrc (n entries; gsrc may be null)       stage gradients
+//   x_0    : x0 if usex0 else 0                               prescribed initial state
+//   cdyn   : cs * csrc (T*nx; csrc may be null)               dynamics offsets
+//   useb   : fixed binaries take their value v (constant direction) or 0
+//   S.e    : D .* rhs_c on entry ; the multiplier step dz on exit
+// ---------------------------------------------------------------------------------------------
+__device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double *gsrc, double gs, bool usex0,
+                          const double *csrc, double cs, bool useb, double *dw, double *dlam, double *dnuf)
+{
+    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub;
+    // g = rhs_d + C' e  (column lists)
+    for (int o = lane; o < T * nz; o += WAVE) {
+        const int t = o / nz, j = o - t * nz;
+        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+        const double *et = S.e + t * p.mreg;
+        double a = gsrc ? gs * gsrc[o] : 0.0;
+        for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * et[st.crow[k]];
+        S.g[o] = a;
+    }
+    for (int j = lane; j < nx; j += WAVE) {
+        const double a = gsrc ? gs * gsrc[T * nz + j] : 0.0;
+        S.g[T * nz + j] = a;
+        S.pv[T * nx + j] = -a;
+    }
+    __syncthreads();
+    // backward sweep
+    for (int t = T - 1; t >= 0; t--) {
+        const double *Pn = S.Pr + (t + 1) * nx * nx;
+        for (int i = lane; i < nx; i += WAVE) {
+            double a = S.pv[(t + 1) * nx + i];
+            if (csrc)
+                for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * cs * csrc[t * nx + l];
+            S.q[i] = a;
+        }
+        __syncthreads();
+        for (int j = lane; j < nz; j += WAVE) {
+            double a = -S.g[t * nz + j];
+            for (int l = 0; l < nx; l++) a += AB(p, l, j) * S.q[l];
+            if (useb) a += S.mb[t * nz + j];
+            if (j >= nx + nuc) {
+                const int f = S.fix[t * nub + (j - nx - nuc)];
+                if (f >= 0) a = (useb && f == 1) ? -1.0 : 0.0;
+            }
+            S.mv[j] = a;
+            if (j >= nx) S.mus[t * nu + (j - nx)] = a;
+        }
+        __syncthreads();
+        for (int i = lane; i < nx; i += WAVE) {
+            double a = S.mv[i];
+            for (int l = 0; l < nu; l++) a -= S.Kg[t * nu * nx + l * nx + i] * S.mv[nx + l];
+            S.pv[t * nx + i] = a;
+        }
+        __syncthreads();
+    }
+    // forward sweep
+    for (int i = lane; i < nx; i += WAVE) dw[i] = usex0 ? S.x0[i] : 0.0;
+    __syncthreads();
+    for (int t = 0; t < T; t++) {
+        const double *x = dw + t * nz;
+        for (int i = lane; i < nu; i += WAVE) {
+            double a = 0;
+            for (int l = 0; l < nx; l++) a += S.Kg[t * nu * nx + i * nx + l] * x[l];
+            for (int l = 0; l < nu; l++) a += S.Minv[t * nu * nu + i * nu + l] * S.mus[t * nu + l];
+            dw[t * nz + nx + i] = -a;
+        }
+        __syncthreads();
+        for (int i = lane; i < nx; i += WAVE) {
+            double a = csrc ? cs * csrc[t * nx + i] : 0.0;
+            for (int l = 0; l < nz; l++) a += AB(p, i, l) * dw[t * nz + l];
+            dw[(t + 1) * nz + i] = a;
+        }
+        __syncthreads();
+    }
+    // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
+    for (int o = lane; o < (T + 1) * nx; o += WAVE) {
+        const int t = o / nx, i = o - t * nx;
+        double a = S.pv[o];
+        for (int l = 0; l < nx; l++) a += S.Pr[t * nx * nx + i * nx + l] * dw[t * nz + l];
+        dlam[o] = -a;
+    }
+    for (int r = lane; r < p.M; r += WAVE) {
+        int t, lr;
+        row_decode(p, r, t, lr);
+        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+        double a = 0;
+        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * dw[t * nz + st.rcol[k]];
+        S.e[r] = S.D[r] * a - S.e[r];
+    }
+    __syncthreads();
+    // multipliers of the fixed binaries from the stationarity row of their component
+    for (int o = lane; o < T * nub; o += WAVE) {
+        const int t = o / nub, b = o - t * nub;
+        double a = 0;
+        if (S.fix[o] >= 0) {
+            const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+            const int c = nx + nuc + b;
+            a = gsrc ? gs * gsrc[t * nz + c] : 0.0;
+            for (int j = 0; j < nz; j++) a -= p.P[c * nz + j] * dw[t * nz + j];
+            for (int k = st.cptr[c]; k < st.cptr[c + 1]; k++) a -= st.cval[k] * S.e[t * p.mreg + st.crow[k]];
+            for (int l = 0; l < nx; l++) a += p.B[l * nu + (c - nx)] * dlam[(t + 1) * nx + l];
+        }
+        dnuf[o] = a;
+    }
+    __syncthreads();
+}
+
+// f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
+__device__ double lin_obj(const DevProb &p, const Lds &S, int lane, const double *lam, const double *nuf, const double *zrow)
+{
+    double a = 0;
+    for (int j = lane; j < p.nx; j += WAVE) a += S.x0[j] * lam[j];
+    for (int o = lane; o < p.T * p.nub; o += WAVE)
+        if (S.fix[o] == 1) a += nuf[o];
+    for (int r = lane; r < p.M; r += WAVE) {
+        int t, lr;
+        row_decode(p, r, t, lr);
+        a += p.st[t < p.T - 1 ? 0 : 1].h[lr] * zrow[r];
+    }
+    return wave_sum(a);
+}
+
+__device__ void set_prescribed(const DevProb &p, const Lds &S, int lane, double tau)
+{
+    for (int i = lane; i < p.nx; i += WAVE) S.w[i] = S.x0[i] * tau;
+    for (int o = lane; o < p.T * p.nub; o += WAVE)
+        if (S.fix[o] >= 0) S.w[(o / p.nub) * p.nz + p.nx + p.nuc + (o % p.nub)] = S.fix[o] * tau;
+}
+
+// One interior-point solve of the node with / without the terminal-set rows.
+// Returns status; tau, iteration count and the largest terminal-row value through references.
+__device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int term_on, int &iters,
+                         double &tau_out, double *trace)
+{
+    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub, M = p.M, n = p.n;
+    int mact = 0;
+    for (int r = lane; r < M; r += WAVE) {
+        int t, lr;
+        row_decode(p, r, t, lr);
+        const bool on = row_active(p, S.fix, t, lr, term_on);
+        mact += on;
+        R.s[r] = 1.0;
+        S.z[r] = on ? 1.0 : 0.0;
+    }
+    mact = (int)wave_sum((double)mact);
+    for (int i = lane; i < n; i += WAVE) S.w[i] = 0.0;
+    for (int i = lane; i < (T + 1) * nx; i += WAVE) S.lam[i] = 0.0;
+    for (int i = lane; i < T * nub; i += WAVE) S.nuf[i] = 0.0;
+    double tau = 1.0, kap = 1.0;
+    __syncthreads();
+    set_prescribed(p, S, lane, tau);
+    __syncthreads();
+    double x0inf = 0;
+    for (int i = lane; i < nx; i += WAVE) x0inf = fmax(x0inf, fabs(S.x0[i]));
+    x0inf = wave_max(x0inf);
+
+    int status = HMPC_MAXITER, it = 0;
+    for (it = 0; it <= p.max_iter; it++) {
+        // ---------------- residuals ----------------
+        double wPw = 0;
+        for (int o = lane; o < n; o += WAVE) {
+            const int t = o / nz < T ? o / nz : T;
+            const int i = o - t * nz, dim = t < T ? nz : nx;
+            const double *PP = t < T ? p.P : p.PT;
+            double a = 0;
+            for (int j = 0; j < dim; j++) a += PP[i * dim + j] * S.w[t * nz + j];
+            S.Pw[o] = a;
+            wPw += a * S.w[o];
+        }
+        wPw = wave_sum(wPw);
+        double rdinf = 0, certinf = 0, fy = 0, winf = 0, yinf = 0;
+        for (int o = lane; o < n; o += WAVE) {
+            const int t = o / nz < T ? o / nz : T;
+            const int j = o - t * nz;
+            double a = 0; // E'y + C'z
+            if (t == T) {
+                a = S.lam[T * nx + j];
+            } else {
+                const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+                if (j < nx) a += S.lam[t * nx + j];
+                for (int l = 0; l < nx; l++) a -= AB(p, l, j) * S.lam[(t + 1) * nx + l];
+                if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
+                for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * S.z[t * p.mreg + st.crow[k]];
+            }
+            const double v = S.Pw[o] + a;
+            S.rd[o] = v;
+            rdinf = fmax(rdinf, fabs(v));
+            certinf = fmax(certinf, fabs(a));
+            winf = fmax(winf, fabs(S.w[o]));
+        }
+        for (int o = lane; o < T * nx; o += WAVE) {
+            const int t = o / nx, i = o - t * nx;
+            double a = S.w[(t + 1) * nz + i];
+            for (int l = 0; l < nz; l++) a -= AB(p, i, l) * S.w[t * nz + l];
+            S.rdyn[o] = a;
+        }
+        double rcinf = 0, hz = 0, sz = 0, zinf = 0;
+        for (int r = lane; r < M; r += WAVE) {
+            int t, lr;
+            row_decode(p, r, t, lr);
+            const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+            double a = 0;
+            if (row_active(p, S.fix, t, lr, term_on)) {
+                const double zr = S.z[r], sr = R.s[r];
+                a = sr - st.h[lr] * tau;
+                for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * S.w[t * nz + st.rcol[k]];
+                hz += st.h[lr] * zr;
+                sz += sr * zr;
+                zinf = fmax(zinf, zr);
+            }
+            R.rc[r] = a;
+            rcinf = fmax(rcinf, fabs(a));
+        }
+        __syncthreads(); // rdyn visible
+        for (int o = lane; o < T * nx; o += WAVE) rcinf = fmax(rcinf, fabs(S.rdyn[o]));
+        for (int o = lane; o < (T + 1) * nx; o += WAVE) yinf = fmax(yinf, fabs(S.lam[o]));
+        for (int o = lane; o < T * nub; o += WAVE) {
+            yinf = fmax(yinf, fabs(S.nuf[o]));
+            if (S.fix[o] == 1) fy += S.nuf[o];
+        }
+        for (int j = lane; j < nx; j += WAVE) fy += S.x0[j] * S.lam[j];
+        rdinf = wave_max(rdinf); certinf = wave_max(certinf); winf = wave_max(winf);
+        rcinf = wave_max(rcinf); zinf = wave_max(fmax(zinf, yinf));
+        fy = wave_sum(fy); hz = wave_sum(hz); sz = wave_sum(sz);
+        const double rg = wPw / tau + fy + hz + kap;
+        const double mu = (sz + tau * kap) / (mact + 1);
+
+        // ---------------- termination ----------------
+        const double pobj = 0.5 * wPw / (tau * tau), dob = -0.5 * wPw / (tau * tau) - (fy + hz) / tau;
+        const double gap = fabs(pobj - dob), eta = -(fy + hz);
+        if (trace && lane == 0 && it < 64) {
+            double *tr = trace + it * 8;
+            tr[0] = tau; tr[1] = kap; tr[2] = mu; tr[3] = rcinf / tau; tr[4] = rdinf / tau; tr[5] = gap; tr[6] = eta; tr[7] = certinf;
+        }
+        if (rcinf / tau <= p.tol * (1 + winf / tau + x0inf) && rdinf / tau <= p.tol * (1 + zinf / tau) &&
+            gap <= p.tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
+            status = HMPC_OPTIMAL;
+            break;
+        }
+        if (eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
+            status = HMPC_INFEASIBLE;
+            break;
+        }
+        if (it == p.max_iter) break;
+
+        // ---------------- factorisation ----------------
+        for (int r = lane; r < M; r += WAVE) {
+            int t, lr;
+            row_decode(p, r, t, lr);
+            S.D[r] = row_active(p, S.fix, t, lr, term_on) ? S.z[r] / R.s[r] : 0.0;
+        }
+        __syncthreads();
+        if (factor(p, S, lane) != 0) { status = HMPC_NUMERICAL; break; }
+
+        // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
+        for (int r = lane; r < M; r += WAVE) {
+            int t, lr;
+            row_decode(p, r, t, lr);
+            S.e[r] = S.D[r] * p.st[t < T - 1 ? 0 : 1].h[lr];
+        }
+        __syncthreads();
+        kkt_solve(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1);
+        double g1 = 0;
+        for (int o = lane; o < n; o += WAVE) g1 += S.Pw[o] * S.w1[o];
+        g1 = wave_sum(g1) * 2.0 / tau;
+        for (int r = lane; r < M; r += WAVE) R.z1[r] = S.e[r];
+        const double fyhz1 = lin_obj(p, S, lane, S.lam1, S.nuf1, S.e);
+        const double den = kap / tau + wPw / (tau * tau) - g1 - fyhz1;
+
+        double dtau_a = 0, dkap_a = 0, sigma = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const double lin = pass == 0 ? 1.0 : 1.0 - sigma;
+            const double dkap_rhs = tau * kap + (pass ? dtau_a * dkap_a - sigma * mu : 0.0);
+            __syncthreads();
+            for (int r = lane; r < M; r += WAVE) {
+                double v = 0;
+                if (S.D[r] != 0.0) { // active row
+                    const double dsr = R.s[r] * S.z[r] + (pass ? R.prod[r] - sigma * mu : 0.0);
+                    v = S.D[r] * (-lin * R.rc[r] + dsr / S.z[r]);
+                }
+                S.e[r] = v;
+            }
+            __syncthreads();
+            kkt_solve(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2);
+            double g2 = 0;
+            for (int o = lane; o < n; o += WAVE) g2 += S.Pw[o] * S.w2[o];
+            g2 = wave_sum(g2) * 2.0 / tau;
+            const double fyhz2 = lin_obj(p, S, lane, S.lam2, S.nuf2, S.e);
+            const double dtau = (lin * rg - dkap_rhs / tau + g2 + fyhz2) / den;
+            const double dkap = -(dkap_rhs + kap * dtau) / tau;
+            // combined direction d = v2 + dtau v1
+            for (int o = lane; o < n; o += WAVE) S.w2[o] += dtau * S.w1[o];
+            for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += dtau * S.lam1[o];
+            for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += dtau * S.nuf1[o];
+            for (int r = lane; r < M; r += WAVE) {
+                const double v = S.D[r] != 0.0 ? S.e[r] + dtau * R.z1[r] : 0.0;
+                S.e[r] = v;
+                R.dz[r] = v;
+            }
+            __syncthreads();
+            if (pass == 1 && p.refine) {
+                // residual of the three linear blocks at the combined direction (x_0 and fixed
+                // binaries are met by construction), then one correction solve
+                for (int o = lane; o < n; o += WAVE) {
+                    const int t = o / nz < T ? o / nz : T;
+                    const int j = o - t * nz, dim = t < T ? nz : nx;
+                    const double *PP = t < T ? p.P : p.PT;
+                    double a = -lin * S.rd[o];
+                    for (int l = 0; l < dim; l++) a -= PP[j * dim + l] * S.w2[t * nz + l];
+                    if (t == T) {
+                        a -= S.lam2[T * nx + j];
+                    } else {
+                        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+                        if (j < nx) a -= S.lam2[t * nx + j];
+                        for (int l = 0; l < nx; l++) a += AB(p, l, j) * S.lam2[(t + 1) * nx + l];
+                        for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a -= st.cval[k] * S.e[t * p.mreg + st.crow[k]];
+                        if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a = 0.0;
+                        if (t == 0 && j < nx) a = 0.0;
+                    }
+                    S.ed[o] = a;
+                }
+                for (int o = lane; o < T * nx; o += WAVE) {
+                    const int t = o / nx, i = o - t * nx;
+                    double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
+                    for (int l = 0; l < nz; l++) a += AB(p, i, l) * S.w2[t * nz + l];
+                    S.edyn[o] = a;
+                }
+                __syncthreads();
+                for (int r = lane; r < M; r += WAVE) {
+                    double v = 0;
+                    if (S.D[r] != 0.0) {
+                        int t, lr;
+                        row_decode(p, r, t, lr);
+                        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+                        const double dsr = R.s[r] * S.z[r] + R.prod[r] - sigma * mu;
+                        double a = -lin * R.rc[r] + dsr / S.z[r] + dtau * st.h[lr] + S.e[r] * R.s[r] / S.z[r];
+                        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a -= st.rval[k] * S.w2[t * nz + st.rcol[k]];
+                        v = S.D[r] * a;
+                    }
+                    S.e[r] = v;
+                }
+                __syncthreads();
+                kkt_solve(p, S, lane, S.ed, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1);
+                for (int o = lane; o < n; o += WAVE) S.w2[o] += S.w1[o];
+                for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += S.lam1[o];
+                for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += S.nuf1[o];
+                for (int r = lane; r < M; r += WAVE)
+                    if (S.D[r] != 0.0) R.dz[r] += S.e[r];
+            }
+            // slack step from the complementarity row ; step to the boundary
+            double amax = 1e30;
+            if (dtau < 0) amax = fmin(amax, -tau / dtau);
+            if (dkap < 0) amax = fmin(amax, -kap / dkap);
+            for (int r = lane; r < M; r += WAVE) {
+                if (S.D[r] == 0.0) continue;
+                const double dz = R.dz[r], sr = R.s[r], zr = S.z[r];
+                const double dsr = sr * zr + (pass ? R.prod[r] - sigma * mu : 0.0);
+                const double ds = -(dsr + sr * dz) / zr;
+                if (dz < 0) amax = fmin(amax, -zr / dz);
+                if (ds < 0) amax = fmin(amax, -sr / ds);
+                if (pass == 0) R.prod[r] = ds * dz;
+                else R.rc[r] = ds; // row residual no longer needed this iteration
+            }
+            amax = wave_min(amax);
+            if (pass == 0) {
+                const double aa = fmin(1.0, amax);
+                sigma = (1 - aa) * (1 - aa) * (1 - aa);
+                dtau_a = dtau;
+                dkap_a = dkap;
+            } else {
+                const double alpha = fmin(1.0, 0.99 * amax);
+                __syncthreads();
+                for (int o = lane; o < n; o += WAVE) S.w[o] += alpha * S.w2[o];
+                for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam[o] += alpha * S.lam2[o];
+                for (int o = lane; o < T * nub; o += WAVE) S.nuf[o] += alpha * S.nuf2[o];
+                for (int r = lane; r < M; r += WAVE)
+                    if (S.D[r] != 0.0) {
+                        S.z[r] += alpha * R.dz[r];
+                        R.s[r] += alpha * R.rc[r];
+                    }
+                tau += alpha * dtau;
+                kap += alpha * dkap;
+                __syncthreads();
+                set_prescribed(p, S, lane, tau);
+                __syncthreads();
+            }
+        }
+        if (!(tau > 0) || !(kap >= 0)) { status = HMPC_NUMERICAL; break; }
+    }
+    iters = it;
+    tau_out = tau;
+    return status;
+}
+
+// Largest value of (scaled terminal row) - h at the current (optimal) iterate.
+__device__ double terminal_violation(const DevProb &p, const Lds &S, int lane, double tau)
+{
+    const SparseStage &st = p.st[1];
+    double tv = -1e300;
+    for (int lr = p.nc + lane; lr < p.ncL; lr += WAVE) {
+        double a = -st.h[lr] * tau;
+        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * S.w[(p.T - 1) * p.nz + st.rcol[k]];
+        tv = fmax(tv, a / tau);
+    }
+    return wave_max(tv);
+}
+
+// Output record in the reference's conventions (subproblem_solution.py:68-168).
+__device__ void write_record(const DevProb &p, const Lds &S, const Rows &R, int lane, int status, double tau,
+                             int qp, const DevOut &out)
+{
+    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nub = p.nub, M = p.M;
+    const int nmu = (T - 1) * p.nc + p.ncL;
+    const bool inf = status == HMPC_INFEASIBLE;
+    double scale;
+    if (inf) {
+        double big = 0;
+        for (int r = lane; r < M; r += WAVE) big = fmax(big, S.z[r]);
+        for (int o = lane; o < (T + 1) * nx; o += WAVE) big = fmax(big, fabs(S.lam[o]));
+        for (int o = lane; o < T * nub; o += WAVE) big = fmax(big, fabs(S.nuf[o]));
+        scale = 1.0 / wave_max(big); // Farkas ray: scale is arbitrary
+    } else {
+        scale = 1.0 / (tau * p.cs);
+    }
+    double *dual = out.dual ? out.dual + (size_t)qp * p.n_dual : nullptr;
+    double *prim = out.primal ? out.primal + (size_t)qp * p.n_primal : nullptr;
+    const int o_mu = (T + 1) * nx, o_lb = o_mu + nmu, o_ub = o_lb + T * nub, o_rho = o_ub + T * nub;
+    const int o_sig = o_rho + T * p.nq + p.nqT;
+    double farkas = 0;
+    for (int o = lane; o < (T + 1) * nx; o += WAVE) {
+        const double v = S.lam[o] * scale;
+        if (dual) dual[o] = v;
+        if (o < nx) farkas -= S.x0[o] * v;
+    }
+    for (int r = lane; r < M; r += WAVE) {
+        int t, lr;
+        row_decode(p, r, t, lr);
+        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
+        const int mg = t < T - 1 ? p.nc : p.ncL;
+        if (lr < mg) {
+            const double v = S.z[r] * scale * st.scale[lr];
+            if (dual) dual[o_mu + t * p.nc + lr] = v;
+            farkas -= (st.h[lr] / st.scale[lr]) * v;
+        }
+    }
+    for (int o = lane; o < T * nub; o += WAVE) {
+        const int t = o / nub, b = o - t * nub;
+        const int mg = t < T - 1 ? p.nc : p.ncL;
+        double lo, hi;
+        if (S.fix[o] < 0) {
+            lo = S.z[t * p.mreg + mg + b] * scale;
+            hi = S.z[t * p.mreg + mg + nub + b] * scale;
+            farkas -= hi;
+        } else {
+            const double v = S.nuf[o] * scale;
+            hi = v > 0 ? v : 0.0;
+            lo = v < 0 ? -v : 0.0;
+            farkas -= S.fix[o] * (hi - lo);
+        }
+        if (dual) { dual[o_lb + o] = lo; dual[o_ub + o] = hi; }
+    }
+    farkas = wave_sum(farkas);
+    double cost = 0, dq = 0;
+    if (inf) {
+        if (prim) for (int o = lane; o < p.n_primal; o += WAVE) prim[o] = __longlong_as_double(0x7ff8000000000000LL);
+        if (dual) for (int o = o_rho + lane; o < p.n_dual; o += WAVE) dual[o] = 0.0;
+    } else {
+        if (prim) {
+            for (int o = lane; o < (T + 1) * nx; o += WAVE) prim[o] = S.w[(o / nx) * nz + (o % nx)] / tau;
+            for (int o = lane; o < T * nu; o += WAVE) prim[(T + 1) * nx + o] = S.w[(o / nu) * nz + nx + (o % nu)] / tau;
+        }
+        for (int o = lane; o < T * p.nq + p.nqT; o += WAVE) {
+            const int t = o / p.nq < T ? o / p.nq : T;
+            const int r = o - t * p.nq;
+            const double *QQ = t < T ? p.Q : p.QT;
+            double a = 0;
+            for (int j = 0; j < nx; j++) a += QQ[r * nx + j] * S.w[t * nz + j];
+            a /= tau;
+            if (dual) dual[o_rho + o] = 2 * a;
+            cost += a * a;
+        }
+        for (int o = lane; o < T * p.nr; o += WAVE) {
+            const int t = o / p.nr, r = o - t * p.nr;
+            double a = 0;
+            for (int j = 0; j < nu; j++) a += p.R[r * nu + j] * S.w[t * nz + nx + j];
+            a /= tau;
+            if (dual) dual[o_sig + o] = 2 * a;
+            cost += a * a;
+        }
+        cost = wave_sum(cost);
+        dq = 4.0 * cost; // sum rho^2 + sigma^2
+    }
+    if (lane == 0) {
+        if (out.obj) out.obj[qp] = inf ? __longlong_as_double(0x7ff0000000000000LL) : cost;
+        if (out.dual_obj) out.dual_obj[qp] = inf ? farkas : -0.25 * dq + farkas;
+        if (out.status) out.status[qp] = status;
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(WAVE)
+hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
+               const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nub = p.nub, M = p.M, n = p.n;
+    Lds S;
+    {
+        double *q = reinterpret_cast<double *>(smem);
+        auto take = [&](int cnt) { double *r = q; q += cnt; return r; };
+        S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
+        S.z = take(M); S.D = take(M); S.e = take(M);
+        S.Minv = take(T * nu * nu); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nx * nx);
+        S.mb = take(T * nz); S.mus = take(T * nu);
+        S.rd = take(n); S.rdyn = take(T * nx); S.Pw = take(n); S.g = take(n); S.pv = take((T + 1) * nx);
+        S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
+        S.w2 = take(n); S.lam2 = take((T + 1) * nx); S.nuf2 = take(T * nub);
+        S.ed = take(n); S.edyn = take(T * nx);
+        S.Mm = take(nz * nz); S.E = take(nz * nu); S.PA = take(nx * nz); S.q = take(nx); S.mv = take(nz);
+        S.x0 = take(nx);
+        S.fix = reinterpret_cast<int *>(q);
+    }
+    Rows R;
+    {
+        double *base = rows_ws + (size_t)blockIdx.x * 5 * p.Mpad;
+        R.s = base; R.rc = base + p.Mpad; R.z1 = base + 2 * p.Mpad; R.dz = base + 3 * p.Mpad; R.prod = base + 4 * p.Mpad;
+    }
+    for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
+        __syncthreads();
+        for (int o = lane; o < T * nub; o += WAVE) S.fix[o] = fixg[(size_t)qp * T * nub + o];
+        for (int i = lane; i < nx; i += WAVE) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
+        __syncthreads();
+        int it1 = 0, it2 = 0, status;
+        double tau = 1.0;
+        double *tr = (trace && qp == 0) ? trace : nullptr;
+        if (p.ncL > p.nc && p.lazy) {
+            // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for
+            // the node and carries no terminal multipliers; an optimum that satisfies the masked
+            // rows strictly is the node's optimum.  Otherwise solve again with every row.
+            status = ipm_solve(p, S, R, lane, 0, it1, tau, tr);
+            bool done = status == HMPC_INFEASIBLE;
+            if (status == HMPC_OPTIMAL) done = terminal_violation(p, S, lane, tau) < 0.0;
+            if (!done) status = ipm_solve(p, S, R, lane, 1, it2, tau, tr ? tr + 64 * 8 : nullptr);
+        } else {
+            status = ipm_solve(p, S, R, lane, 1, it1, tau, tr);
+        }
+        __syncthreads();
+        write_record(p, S, R, lane, status, tau, qp, out);
+        if (lane == 0 && out.iters) out.iters[qp] = it1 + it2;
+    }
+}

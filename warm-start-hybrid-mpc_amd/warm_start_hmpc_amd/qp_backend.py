@@ -1,0 +1,170 @@
+"""ctypes binding of the HIP library (``libhmpc.so``, C ABI in ``include/hmpc.h``).
+
+This is the product path: there is no CPU fallback.  If the shared library is
+missing, or no GPU is present, construction raises.  The library replaces the
+reference's ``BoundedQP`` (a ``gurobipy.Model`` subclass,
+``warm_start_hmpc/bounded_qp.py:5``) on the QP-relaxation path: where the
+reference edits the right-hand sides of one Gurobi model per node and calls
+``optimize`` (``controller.py:254-267``), ``solve_batch`` hands a whole
+frontier of nodes to one kernel launch.
+"""
+import ctypes
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(os.path.dirname(_HERE), 'libhmpc.so')
+
+STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_MAXITER, STATUS_NUMERICAL = 0, 1, 2, 3
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int32)
+
+
+class _Problem(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ('nx', 'nu', 'nub', 'T', 'nc', 'ncT', 'nq', 'nr', 'nqT')] + \
+               [(k, _dp) for k in ('A', 'B', 'F', 'G', 'h', 'F_Tm1', 'G_Tm1', 'h_Tm1', 'Q', 'R', 'Q_T')]
+
+
+class _Options(ctypes.Structure):
+    _fields_ = [('tol', ctypes.c_double), ('tol_inf', ctypes.c_double), ('max_iter', ctypes.c_int32),
+                ('lazy_terminal', ctypes.c_int32), ('refine', ctypes.c_int32), ('device', ctypes.c_int32)]
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [('obj', ctypes.c_void_p), ('dual_obj', ctypes.c_void_p), ('status', ctypes.c_void_p),
+                ('iters', ctypes.c_void_p), ('primal', ctypes.c_void_p), ('dual', ctypes.c_void_p)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libhmpc.so once; raises if it has not been built (``__graft_entry__.build()``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBRARY_PATH):
+            raise RuntimeError('HIP library %s not found: build it with __graft_entry__.build() '
+                               '(make -C warm-start-hybrid-mpc_amd/csrc). There is no CPU fallback.' % LIBRARY_PATH)
+        lib = ctypes.CDLL(LIBRARY_PATH)
+        lib.hmpc_create.restype = ctypes.c_int
+        lib.hmpc_create.argtypes = [ctypes.POINTER(_Problem), ctypes.POINTER(_Options), ctypes.POINTER(ctypes.c_void_p)]
+        lib.hmpc_destroy.restype = ctypes.c_int
+        lib.hmpc_destroy.argtypes = [ctypes.c_void_p]
+        lib.hmpc_record_sizes.restype = ctypes.c_int
+        lib.hmpc_record_sizes.argtypes = [ctypes.c_void_p, _ip, _ip]
+        lib.hmpc_launch_info.restype = ctypes.c_int
+        lib.hmpc_launch_info.argtypes = [ctypes.c_void_p, _ip, _ip]
+        lib.hmpc_solve_batch.restype = ctypes.c_int
+        lib.hmpc_solve_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                         ctypes.c_int32, ctypes.POINTER(_Result)]
+        lib.hmpc_solve_batch_device.restype = ctypes.c_int
+        lib.hmpc_solve_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                                ctypes.c_int32, ctypes.POINTER(_Result), ctypes.c_void_p]
+        lib.hmpc_last_error.restype = ctypes.c_char_p
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info',
+                    'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error')
+
+
+class HipBatchedQP(object):
+    """Batched QP-relaxation solver on one MI355X.
+
+    problem : dict as returned by ``HybridModelPredictiveController.problem_data()``
+    tol, tol_inf, max_iter, lazy_terminal, refine : see ``hmpc_options`` in include/hmpc.h
+    device : HIP device ordinal (-1: current device)
+    """
+
+    def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, lazy_terminal=True, refine=True, device=-1):
+        self.lib = load_library()
+        keep = {}
+        for k in ('A', 'B', 'F', 'G', 'F_Tm1', 'G_Tm1', 'Q', 'R', 'Q_T'):
+            keep[k] = np.ascontiguousarray(np.atleast_2d(problem[k]), dtype=np.float64)
+        for k in ('h', 'h_Tm1'):
+            keep[k] = np.ascontiguousarray(problem[k], dtype=np.float64).reshape(-1)
+        nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
+        shapes = {'A': (nx, nx), 'B': (nx, nu), 'F': (keep['h'].size, nx), 'G': (keep['h'].size, nu),
+                  'F_Tm1': (keep['h_Tm1'].size, nx), 'G_Tm1': (keep['h_Tm1'].size, nu),
+                  'Q': (keep['Q'].shape[0], nx), 'R': (keep['R'].shape[0], nu), 'Q_T': (keep['Q_T'].shape[0], nx)}
+        for k, shp in shapes.items():
+            if keep[k].shape != shp:
+                raise ValueError('Matrix %s has shape %s, expected %s.' % (k, keep[k].shape, shp))
+        self._keep = keep
+        p = _Problem(nx=nx, nu=nu, nub=nub, T=T, nc=keep['h'].size, ncT=keep['h_Tm1'].size,
+                     nq=keep['Q'].shape[0], nr=keep['R'].shape[0], nqT=keep['Q_T'].shape[0],
+                     **{k: v.ctypes.data_as(_dp) for k, v in keep.items()})
+        o = _Options(tol=tol, tol_inf=tol_inf, max_iter=int(max_iter), lazy_terminal=int(bool(lazy_terminal)),
+                     refine=int(bool(refine)), device=int(device))
+        handle = ctypes.c_void_p()
+        rc = self.lib.hmpc_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(handle))
+        if rc != 0:
+            msg = self.lib.hmpc_last_error().decode()
+            raise (ValueError if rc == -1 else RuntimeError)('hmpc_create failed (%d): %s' % (rc, msg))
+        self.handle = handle
+        n_primal, n_dual = ctypes.c_int32(), ctypes.c_int32()
+        self.lib.hmpc_record_sizes(self.handle, ctypes.byref(n_primal), ctypes.byref(n_dual))
+        self.n_primal, self.n_dual = n_primal.value, n_dual.value
+        self.nx, self.nfix = nx, T * nub
+
+    def __del__(self):
+        handle = getattr(self, 'handle', None)
+        if handle:
+            self.lib.hmpc_destroy(handle)
+            self.handle = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError('hmpc call failed (%d): %s' % (rc, self.lib.hmpc_last_error().decode()))
+
+    def solve_batch(self, x0, fix, want_primal=True, want_dual=True):
+        """Host arrays in, host arrays out (copies included in ``time``).
+
+        x0 : (nx,) shared or (B, nx); fix : int8 (B, T*nub), -1 free / 0 / 1
+        """
+        fix = np.ascontiguousarray(fix, dtype=np.int8)
+        if fix.ndim != 2 or fix.shape[1] != self.nfix:
+            raise ValueError('fix must have shape (B, %d).' % self.nfix)
+        B = fix.shape[0]
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        if x0.shape == (self.nx,):
+            stride = 0
+        elif x0.shape == (B, self.nx):
+            stride = self.nx
+        else:
+            raise ValueError('x0 must have shape (%d,) or (%d, %d).' % (self.nx, B, self.nx))
+        out = dict(obj=np.empty(B), dual_obj=np.empty(B), status=np.empty(B, dtype=np.int32),
+                   iters=np.empty(B, dtype=np.int32),
+                   primal=np.empty((B, self.n_primal)) if want_primal else None,
+                   dual=np.empty((B, self.n_dual)) if want_dual else None)
+        res = _Result(**{k: (v.ctypes.data if v is not None else None) for k, v in out.items()})
+        tic = time.perf_counter()
+        self._check(self.lib.hmpc_solve_batch(self.handle, x0.ctypes.data, stride, fix.ctypes.data, B, ctypes.byref(res)))
+        out['time'] = time.perf_counter() - tic
+        return out
+
+    def solve_batch_device(self, x0, fix, out, stream=None):
+        """Device-resident form: torch CUDA tensors in and out, asynchronous on ``stream``
+        (default: torch's current stream).  ``out`` is a dict of preallocated tensors with keys
+        obj, dual_obj (float64 [B]), status, iters (int32 [B]), primal [B, n_primal], dual [B, n_dual]
+        (the last two may be None)."""
+        import torch
+        B = fix.shape[0]
+        assert fix.dtype == torch.int8 and fix.is_cuda and fix.is_contiguous() and fix.shape[1] == self.nfix
+        assert x0.dtype == torch.float64 and x0.is_cuda and x0.is_contiguous()
+        stride = 0 if x0.dim() == 1 else self.nx
+        res = _Result(**{k: (out[k].data_ptr() if out.get(k) is not None else None)
+                         for k in ('obj', 'dual_obj', 'status', 'iters', 'primal', 'dual')})
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        self._check(self.lib.hmpc_solve_batch_device(self.handle, x0.data_ptr(), stride, fix.data_ptr(), B,
+                                                     ctypes.byref(res), ctypes.c_void_p(stream)))
+
+    def launch_info(self):
+        grid, lds = ctypes.c_int32(), ctypes.c_int32()
+        self.lib.hmpc_launch_info(self.handle, ctypes.byref(grid), ctypes.byref(lds))
+        return grid.value, lds.value
