@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- QP subproblems/s of the batched B&B-node solver on MI355X.
+
+A "step" is one pass of the hot path over one synthetic frontier: every rank
+solves ``--frontier`` random-prefix nodes of the cart-pole-with-walls MIQP
+(N=20, 4 binaries/step; BASELINE.json configs[1], frontier generator of
+SURVEY.md 8(d) C2) with inputs already resident in HBM, then -- when more than
+one rank runs -- all ranks exchange the incumbent upper bound with one RCCL
+all-reduce(min) of 8 bytes.  Frontier nodes are independent, so ranks hold
+disjoint shards and the scaling is weak (fixed work per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frontier B]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(ctrl, x0, fix):
+    """The CPU oracle (a float64 port of the same QP statement, oracle/hsde_qp.c) timed on the
+    host cores of this box, on the same frontier.  A reported baseline, not the thing shipped."""
+    from oracle.oracle_qp import OracleBatchedQP
+    cores = os.cpu_count() or 1
+    orc = OracleBatchedQP(ctrl.problem_data(), threads=cores)
+    orc.solve_batch(x0, fix[:min(64, len(fix))])
+    best = None
+    for _ in range(2):
+        t = time.perf_counter()
+        orc.solve_batch(x0, fix)
+        dt = time.perf_counter() - t
+        best = dt if best is None else min(best, dt)
+    one = OracleBatchedQP(ctrl.problem_data(), threads=1)
+    sub = fix[:min(512, len(fix))]
+    t = time.perf_counter()
+    one.solve_batch(x0, sub)
+    t1 = time.perf_counter() - t
+    return {'value': len(fix) / best, 'unit': 'QP subproblems/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d-node frontier of this run, OpenMP over nodes, best of 2' % len(fix),
+            'single_thread_value': len(sub) / t1}
+
+
+def mpc_steps_per_sec(ctrl, steps=10):
+    """Closed-loop MPC steps/s (warm-started B&B, sigma = 0), a secondary figure of BASELINE.json's metric."""
+    x = np.array([0., 0., 1., 0.])
+    ws = None
+    solves = []
+    t0 = None
+    for k in range(steps + 1):
+        if k == 1:
+            t0 = time.perf_counter()  # step 0 is the cold start
+        u0, ws, info = ctrl.feedback(x, warm_start=ws, frontier_width=32)
+        if u0 is None:
+            break
+        solves.append(info['qp_solves'])
+        x = info['x1']
+    dt = time.perf_counter() - t0
+    return (len(solves) - 1) / dt, solves
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--frontier', type=int, default=4096, help='nodes per GPU per step')
+    ap.add_argument('--p-one', type=float, default=0.5)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from helpers import make_controller, random_prefix_frontier
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    ctrl = make_controller('cart_pole_with_walls', backend='hip', device=local)
+    T, nub = ctrl.T, ctrl.mld.nub
+    B = args.frontier
+    # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1
+    fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
+    x0_h = np.array([0., 0., 1., 0.])
+    fix = torch.from_numpy(fix_h).to(dev)
+    x0 = torch.from_numpy(x0_h).to(dev)
+    out = dict(obj=torch.empty(B, dtype=torch.float64, device=dev), dual_obj=torch.empty(B, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
+               primal=torch.empty(B, ctrl.qp.n_primal, dtype=torch.float64, device=dev),
+               dual=torch.empty(B, ctrl.qp.n_dual, dtype=torch.float64, device=dev))
+    fully_fixed = torch.from_numpy((fix_h >= 0).all(axis=1)).to(dev)
+    ub = torch.full((1,), float('inf'), dtype=torch.float64, device=dev)
+
+    def step():
+        ctrl.qp.solve_batch_device(x0, fix, out)
+        # incumbent upper bound = best objective among binary-feasible (fully fixed) nodes,
+        # shared over xGMI so that every rank prunes against the global best
+        cand = torch.where(fully_fixed, out['obj'], torch.full_like(out['obj'], float('inf')))
+        torch.minimum(ub, cand.min().reshape(1), out=ub)
+        if world > 1:
+            dist.all_reduce(ub, op=dist.ReduceOp.MIN)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        ctrl.qp.solve_batch_device(x0, fix, out)
+        ev[k][1].record()
+        cand = torch.where(fully_fixed, out['obj'], torch.full_like(out['obj'], float('inf')))
+        torch.minimum(ub, cand.min().reshape(1), out=ub)
+        if world > 1:
+            dist.all_reduce(ub, op=dist.ReduceOp.MIN)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    status = out['status'].cpu().numpy()
+    iters = out['iters'].cpu().numpy()
+    if rank == 0:
+        bytes_per_qp = ctrl.layout.bytes_per_qp()
+        value = world * B * args.steps / elapsed
+        achieved = bytes_per_qp * B / (kernel_ms * 1e-3) / 1e9
+        grid, lds = ctrl.qp.launch_info()
+        line = {
+            'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier',
+            'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'cart_pole_with_walls N=20, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), '
+                                   'p_one=%.2f' % args.p_one,
+                       'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist(), 'parallelism': 'frontier sharded by node, '
+                       'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
+                       'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, 1 refinement step'},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_qp': bytes_per_qp, 'kernel': 'hmpc_qp_kernel',
+                         'kernel_ms_avg': kernel_ms, 'grid': grid, 'lds_bytes_per_wg': lds},
+            'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
+                      'not_converged': int((status > 1).sum()), 'ipm_iters_mean': float(iters.mean())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
+            try:
+                sps, solves = mpc_steps_per_sec(ctrl)
+                line['mpc_steps_per_sec'] = {'value': sps, 'warm_solves_per_step': solves[1:],
+                                             'note': 'closed loop sigma=0, warm-started B&B, frontier_width=32, host-pointer API'}
+            except Exception as e:  # secondary figure, never hides the main line
+                line['mpc_steps_per_sec'] = {'error': str(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,60 @@
+"""The C-ABI shared library: it loads, exports every symbol of include/hmpc.h, and the product
+path fails loudly (no CPU fallback) where there is no GPU.  No compute calls here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import make_controller, _NoBackend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_library_exports_header_symbols():
+    from warm_start_hmpc_amd.qp_backend import LIBRARY_PATH, EXPORTED_SYMBOLS
+    if not os.path.exists(LIBRARY_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    header = open(os.path.join(ROOT, 'include', 'hmpc.h')).read()
+    declared = set(re.findall(r'\b(hmpc_[a-z_]+)\s*\(', header))
+    assert declared == set(EXPORTED_SYMBOLS), declared ^ set(EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(LIBRARY_PATH)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    lib.hmpc_last_error.restype = ctypes.c_char_p
+    assert lib.hmpc_last_error() == b''
+
+
+def test_invalid_arguments_are_rejected_without_touching_the_gpu():
+    from warm_start_hmpc_amd.qp_backend import load_library
+    lib = load_library()
+    out = ctypes.c_void_p()
+    assert lib.hmpc_create(None, None, ctypes.byref(out)) == -1      # HMPC_EINVAL
+    assert b'null' in lib.hmpc_last_error()
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend=_NoBackend())
+    bad = ctrl.problem_data()
+    bad['B'] = np.zeros((4, 3))
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    with pytest.raises(ValueError):
+        HipBatchedQP(bad)
+
+
+@pytest.mark.skipif(_has_gpu(), reason='only meaningful on a box without a GPU')
+def test_product_path_fails_loudly_without_gpu():
+    with pytest.raises(RuntimeError):
+        make_controller('cart_pole_with_walls', T=10, backend='hip')
+    # and the controller's default backend is the HIP one
+    from warm_start_hmpc_amd.mld_system import MLDSystem
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from helpers import load_fixture
+    d = load_fixture('cart_pole_with_walls')
+    mld = MLDSystem([d['A'], d['B']], [d['F'], d['G'], d['h']], int(d['nub']))
+    with pytest.raises(RuntimeError):
+        HybridModelPredictiveController(mld, 10, [d['Q'], d['R'], d['Q_T']], None)

@@ -1,0 +1,133 @@
+"""Host-side mirror of the reference API: constructor checks, node <-> bounds, branching rule,
+selection rules, batched frontier mode, feedback().  Runs on the CPU oracle backend."""
+from copy import copy
+
+import numpy as np
+import pytest
+
+from helpers import make_controller, load_fixture, _NoBackend
+from warm_start_hmpc_amd.mld_system import MLDSystem
+from warm_start_hmpc_amd.controller import HybridModelPredictiveController, branch_in_time
+from warm_start_hmpc_amd.branch_and_bound import Node, branch_and_bound, best_first, depth_first, breadth_first
+
+
+def _one_wall():
+    d = load_fixture('cart_pole_one_wall')
+    mld = MLDSystem([d['A'], d['B']], [d['F'], d['G'], d['h']], int(d['nub']))
+    return d, mld, [d['Q'], d['R'], d['Q_T']], [d['F_T'], d['h_T']]
+
+
+def test_init_rejects_wrong_sizes():
+    # reference: test_controller.py:12-38
+    d, mld, objective, terminal = _one_wall()
+    for i, M in enumerate([np.eye(mld.nx + 1), np.eye(mld.nu + 1), np.eye(mld.nx + 1)]):
+        bad = copy(objective)
+        bad[i] = M
+        with pytest.raises(ValueError):
+            HybridModelPredictiveController(mld, 40, bad, terminal, backend=_NoBackend())
+    for i, M in enumerate([np.ones((2 * mld.nx + 1, mld.nx)), np.ones(2 * mld.nx + 1)]):
+        bad = copy(terminal)
+        bad[i] = M
+        with pytest.raises(ValueError):
+            HybridModelPredictiveController(mld, 40, objective, bad, backend=_NoBackend())
+    with pytest.raises(ValueError):
+        MLDSystem([np.eye(3), np.ones((2, 1))], [np.ones((1, 3)), np.ones((1, 1)), np.ones(1)], 0)
+
+
+def test_update_matrices():
+    # reference: test_controller.py:40-59
+    d, mld, objective, terminal = _one_wall()
+    ctrl = HybridModelPredictiveController(mld, 40, objective, terminal, backend=_NoBackend())
+    np.testing.assert_array_equal(ctrl._update['rho'], 1.1 * np.eye(mld.nx))
+    free = HybridModelPredictiveController(mld, 40, objective, [np.empty((0, mld.nx)), np.empty(0)], backend=_NoBackend())
+    np.testing.assert_allclose(free._update['mu'], np.eye(mld.F.shape[0]), atol=1e-12)
+    M = ctrl._update['mu']
+    assert np.min(M) >= 0
+    np.random.seed(1)
+    mu_last = np.random.rand(ctrl.h_Tm1.size)
+    lhs, rhs = np.vstack((mld.F.T, mld.G.T)), np.vstack((ctrl.F_Tm1.T, ctrl.G_Tm1.T))
+    np.testing.assert_array_almost_equal(lhs.dot(M.dot(mu_last)), rhs.dot(mu_last))
+
+
+def test_bound_binaries_and_fix_vector():
+    # reference: test_controller.py:61-82
+    ctrl = make_controller('cart_pole_one_wall', backend=_NoBackend())
+    np.random.seed(1)
+    for _ in range(20):
+        identifier = {(t, np.random.randint(0, 2)): float(np.random.randint(0, 2)) for t in range(ctrl.T)}
+        lo, hi = ctrl._get_bound_binaries(identifier)
+        fix = ctrl._fix_vector(identifier).reshape(ctrl.T, 2)
+        for t in range(ctrl.T):
+            for i in range(2):
+                if (t, i) in identifier:
+                    assert lo[t, i] == hi[t, i] == identifier[(t, i)] == fix[t, i]
+                else:
+                    assert (lo[t, i], hi[t, i], fix[t, i]) == (0., 1., -1)
+
+
+def test_branch_in_time():
+    assert branch_in_time({}, 4) == [{(0, 0): 0.}, {(0, 0): 1.}]
+    assert branch_in_time({(0, 0): 1.}, 4) == [{(0, 1): 0.}, {(0, 1): 1.}]
+    ident = {(0, i): 0. for i in range(4)}
+    assert branch_in_time(ident, 4) == [{(1, 0): 0.}, {(1, 0): 1.}]
+    ident.update({(1, 0): 1., (1, 1): 0.})
+    assert branch_in_time(ident, 4) == [{(1, 2): 0.}, {(1, 2): 1.}]
+
+
+def test_selection_rules():
+    nodes = [Node({}, lb) for lb in (3., 1., 1., 2.)]
+    assert best_first(nodes) is nodes[1]        # first wins ties (branch_and_bound.py:561)
+    assert depth_first(nodes) is nodes[-1]
+    assert breadth_first(nodes) is nodes[0]
+
+
+def test_branch_and_bound_on_a_toy_problem():
+    # minimise sum of costs over 3 binaries, with 'infeasible' combinations; known optimum
+    cost = {0: (1., 3.), 1: (2., .5), 2: (4., 1.)}
+
+    def solver(identifier, cutoff, extra):
+        if identifier.get(0) == 1. and identifier.get(1) == 1.:
+            return np.inf, len(identifier) == 3, 0., None
+        lb = sum(cost[k][int(v)] for k, v in identifier.items()) + sum(min(cost[k]) for k in cost if k not in identifier)
+        return lb, len(identifier) == 3, 0., None
+
+    def brancher(parent):
+        k = len(parent.identifier)
+        return [Node({**parent.identifier, k: 0.}, parent.lb), Node({**parent.identifier, k: 1.}, parent.lb)]
+
+    for rule in (best_first, depth_first, breadth_first):
+        for width in (1, 3):
+            inc, leaves, solves, _ = branch_and_bound(solver, rule, brancher, printing_period=None, frontier_width=width)
+            assert inc.lb == 2.5 and inc.identifier == {0: 0., 1: 1., 2: 1.}
+            assert all(l.lb >= 2.5 for l in leaves)
+
+
+def test_frontier_width_returns_same_incumbent():
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle')
+    x0 = np.array([0., 0., .5, 0.])
+    ref = ctrl.feedforward(x0, printing_period=None)
+    for width in (2, 8, 64):
+        sol, leaves, solves, _ = ctrl.feedforward(x0, printing_period=None, frontier_width=width)
+        assert sol.objective == ref[0].objective
+        assert np.array_equal(np.array(sol.variables['ub']), np.array(ref[0].variables['ub']))
+        assert solves >= ref[2]
+
+
+def test_feedback_closed_loop():
+    ctrl = make_controller('cart_pole_with_walls', backend='oracle')
+    x, ws, costs, solves = np.array([0., 0., 1., 0.]), None, [], []
+    for _ in range(4):
+        u0, ws, info = ctrl.feedback(x, warm_start=ws)
+        assert u0 is not None and u0.shape == (ctrl.mld.nu,)
+        costs.append(info['solution'].objective)
+        solves.append(info['qp_solves'])
+        np.testing.assert_allclose(info['x1'], ctrl.mld.A.dot(x) + ctrl.mld.B.dot(u0), atol=1e-6)
+        x = info['x1']
+    assert all(a > b for a, b in zip(costs, costs[1:]))     # regulation: cost decreases along the closed loop
+    assert solves[0] >= 150 and max(solves[1:]) <= 25       # warm start pays off from the second step on
+
+
+def test_nonconverged_nodes_are_surfaced():
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle', max_iter=3)
+    with pytest.raises(RuntimeError):
+        ctrl._solve_subproblem({}, np.array([0., 0., .5, 0.]))

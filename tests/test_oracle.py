@@ -1,0 +1,157 @@
+"""Pins the CPU oracle (oracle/hsde_qp.c): the reference's known-answer tests for the QP
+boundary, its KKT / cover / lower-bound properties, its published solve counts, and the
+committed golden vectors.  No GPU needed."""
+import numpy as np
+import pytest
+
+from helpers import make_controller, load_fixture, _NoBackend
+from kkt_checks import check_solution, is_disjoint_cover, dual_residuals, dual_objective
+from warm_start_hmpc_amd.mld_system import MLDSystem
+from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+from oracle.oracle_qp import OracleBatchedQP
+
+X0 = np.array([0., 0., 1., 0.])
+
+
+def _generic_qp(n, G, h, R):
+    """min |R u|^2 s.t. G u <= h through the boundary: two identical stages with a dummy state
+    (nx = 1, A = 0, B = 0).  Talks to the backend directly (no controller: the warm-start LPs of
+    its constructor have no meaning for an arbitrary, possibly infeasible, constraint set)."""
+    from warm_start_hmpc_amd.subproblem_solution import RecordLayout, SubproblemSolution
+    m = G.shape[0]
+    prob = dict(nx=1, nu=n, nub=0, T=2, A=np.zeros((1, 1)), B=np.zeros((1, n)), F=np.zeros((m, 1)), G=G, h=h,
+                F_Tm1=np.zeros((m, 1)), G_Tm1=G, h_Tm1=h, Q=np.zeros((1, 1)), R=R, Q_T=np.zeros((1, 1)))
+    res = OracleBatchedQP(prob).solve_batch(np.zeros(1), np.zeros((1, 0), dtype=np.int8))
+    layout = RecordLayout(1, n, 0, 2, m, m, 1, R.shape[0], 1)
+    return SubproblemSolution.from_rows(layout, np.zeros(0, dtype=np.int8), res['obj'][0], res['dual_obj'][0],
+                                        res['status'][0], res['primal'][0], res['dual'][0])
+
+
+def test_known_answer_feasible():
+    # reference: test_bounded_qp.py:104-143 -- min 1/2 |x|^2 s.t. x >= 1, n = 15:
+    # x* = 1, multiplier magnitude 1, objective n/2 (primal = dual)
+    n = 15
+    sol = _generic_qp(n, -np.eye(n), -np.ones(n), np.eye(n) / np.sqrt(2.))
+    # two stages carry the same constraint and cost: each stage reproduces the known answer
+    for t in range(2):
+        np.testing.assert_allclose(sol.primal.variables['uc'][t], np.ones(n), atol=1e-7)
+        np.testing.assert_allclose(sol.dual.variables['mu'][t], np.ones(n), atol=1e-6)
+    assert abs(sol.primal.objective - n) < 1e-6          # 2 stages x n/2
+    assert abs(sol.dual.objective - n) < 1e-6
+    assert np.all(sol.dual.variables['mu'][0] > 0)        # "<=" rows: nonnegative multipliers
+
+
+def test_known_answer_infeasible():
+    # reference: test_bounded_qp.py:145-189 -- x <= a < 0, x >= b > 0: primal None, objective inf,
+    # Farkas proof p >= 0 on "x <= a", q on "-x <= -b" with p == q (their q is -ours), objective -a'p + b'q > 0
+    np.random.seed(1)
+    n = 15
+    a, b = -np.random.rand(n), np.random.rand(n)
+    G = np.vstack((np.eye(n), -np.eye(n)))
+    h = np.concatenate((a, -b))
+    sol = _generic_qp(n, G, h, np.eye(n))
+    assert sol.primal.variables['uc'][0] is None and np.isinf(sol.primal.objective)
+    proof = 0.
+    for t in range(2):
+        p, q = sol.dual.variables['mu'][t][:n], sol.dual.variables['mu'][t][n:]
+        assert np.min(p) >= 0 and np.min(q) >= 0
+        np.testing.assert_allclose(p, q, atol=1e-9 * (1 + np.max(p)))
+        proof += -a.dot(p) + b.dot(q)
+    assert proof > 0
+    assert abs(sol.dual.objective - proof) <= 1e-9 * (1 + proof)
+    assert all(np.all(v == 0) for v in sol.dual.variables['rho'] + sol.dual.variables['sigma'])
+
+
+@pytest.fixture(scope='module')
+def solved():
+    ctrl = make_controller('cart_pole_with_walls', backend='oracle')
+    sol, leaves, solves, _ = ctrl.feedforward(X0, printing_period=None)
+    return ctrl, sol, leaves, solves
+
+
+def test_cold_start_matches_published_counts(solved):
+    ctrl, sol, leaves, solves = solved
+    # reference data: notebooks/cart_pole_with_walls/data/solve_log_sd_0.000.log:8-57 -- 158..161 solves
+    assert 157 <= solves <= 162
+    assert len(leaves) == 81
+    ub = np.array(sol.variables['ub'])
+    assert np.all(ub[:, :2] == 0)                               # left wall never touched
+    assert list(np.flatnonzero(ub[:, 2])) == list(range(10, 17))  # el_r
+    assert list(np.flatnonzero(ub[:, 3])) == list(range(8, 15))   # dam_r
+    assert abs(sol.objective - 0.069257) < 2e-6
+
+
+def test_leaves_certify_themselves(solved):
+    # reference: test_controller.py:84-120 (KKT residuals; leaf bound <= leaf optimum; cover)
+    ctrl, sol, leaves, _ = solved
+    for leaf in leaves:
+        s = ctrl._solve_subproblem(leaf.identifier, X0)[0]
+        check_solution(ctrl, s, leaf.identifier, X0, tol=1e-6)
+        assert s.primal.objective >= leaf.lb - 1e-7
+        assert s.primal.objective >= sol.objective - 1e-7
+    assert is_disjoint_cover(ctrl, leaves)
+
+
+def test_warm_start_properties(solved):
+    # reference: test_controller.py:122-170
+    ctrl, sol, leaves, _ = solved
+    np.random.seed(1)
+    uc0, ub0 = sol.variables['uc'][0], sol.variables['ub'][0]
+    e0 = np.random.randn(ctrl.mld.nx) * .001
+    x1 = ctrl.mld.A.dot(X0) + ctrl.mld.B.dot(np.concatenate((uc0, ub0))) + e0
+    ws = ctrl.construct_warm_start(leaves, X0, uc0, ub0, e0)[0]
+    # published cover size (solve_log_sd_0.000.log:8): 77
+    assert len(ws) == 77
+    assert is_disjoint_cover(ctrl, ws)
+    kept = 0
+    for node in ws:
+        s = ctrl._solve_subproblem(node.identifier, x1)[0]
+        assert s.primal.objective >= node.lb - 1e-7          # implied bounds are valid
+        if node.extra.dual is not None:
+            zero, nonneg = dual_residuals(ctrl, node.extra.dual.variables)
+            assert np.max(np.abs(zero)) < 1e-5 * (1 + np.max(np.abs(np.concatenate(node.extra.dual.variables['mu']))))
+            assert np.min(nonneg) >= -1e-9
+            obj = max(0., dual_objective(ctrl, node.extra.dual.variables, node.identifier, x1))
+            if np.isinf(node.lb):
+                assert obj > 0.
+                kept += 1
+            else:
+                assert abs(obj - node.lb) < 1e-6
+    assert kept >= 70   # the Farkas proofs survive the shift (73-75 of 77)
+    cold = ctrl.feedforward(x1, printing_period=None)
+    warm = ctrl.feedforward(x1, printing_period=None, warm_start=ws)
+    assert warm[0].objective == cold[0].objective             # test_controller.py:165-170 (assertEqual)
+    assert warm[2] <= 25 and cold[2] >= 150                   # published: 10-17 warm, 158-161 cold
+
+
+def test_other_horizons_known_answers():
+    # SURVEY.md Appendix E
+    c10 = make_controller('cart_pole_with_walls', T=10, backend='oracle')
+    sol, leaves, solves, _ = c10.feedforward(X0, printing_period=None)
+    assert sol is None and all(np.isinf(l.lb) for l in leaves)          # N=10 from x0=[0,0,1,0] is infeasible
+    sol, leaves, solves, _ = c10.feedforward(np.array([0., 0., .5, 0.]), printing_period=None)
+    assert abs(sol.objective - 0.0995300) < 1e-6 and np.all(np.array(sol.variables['ub']) == 0)
+    assert (solves, len(leaves)) == (80, 41)
+
+
+def test_golden_vectors():
+    g = load_fixture('qp_golden')
+    for name, fixture in [('n20', 'cart_pole_with_walls'), ('n20dive', 'cart_pole_with_walls'),
+                          ('n10', 'cart_pole_with_walls'), ('onewall', 'cart_pole_one_wall')]:
+        T = int(g[name + '_T'])
+        ctrl = make_controller(fixture, T=T, terminal=bool(g[name + '_terminal']), backend='oracle')
+        res = ctrl.qp.solve_batch(g[name + '_x0'], g[name + '_fix'])
+        assert np.array_equal(res['status'], g[name + '_status'])
+        fin = res['status'] == 0
+        np.testing.assert_allclose(res['obj'][fin], g[name + '_obj'][fin], rtol=1e-7, atol=1e-10)
+        nx = ctrl.mld.nx
+        np.testing.assert_allclose(res['primal'][fin][:, :(T + 1) * nx], g[name + '_x'][fin], rtol=1e-5, atol=1e-7)
+
+
+def test_results_do_not_depend_on_batch_or_threads():
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle')
+    g = load_fixture('qp_golden')
+    fix, x0 = g['n10_fix'], g['n10_x0']
+    a = ctrl.qp.solve_batch(x0, fix)
+    b = OracleBatchedQP(ctrl.problem_data(), threads=4).solve_batch(x0, fix[::-1].copy())
+    assert np.array_equal(a['obj'], b['obj'][::-1]) and np.array_equal(a['dual'], b['dual'][::-1])

@@ -116,8 +116,10 @@ def branch_and_bound(
         Solves a whole frontier in one call to the batched GPU solver.
     frontier_width : int
         Maximum number of candidates solved per round (1 = reference node order).
-    incumbent_exchange : function (ub) -> ub, optional
-        Multi-GPU hook: returns the minimum of the upper bound over all ranks.
+    incumbent_exchange : function (ub, n_candidates) -> (ub, n_candidates), optional
+        Multi-GPU hook, called once per round by every rank: returns the minimum of the upper
+        bound and the total number of open candidates over all ranks (``distributed.py``).
+        The search ends when no rank has a candidate left.
 
     Returns
     -------
@@ -135,7 +137,17 @@ def branch_and_bound(
 
     while True:
         candidates = [l for l in leaves if l.lb < ub - tol]
-        if not candidates:
+        if incumbent_exchange is not None:
+            # every rank takes part in every round, also one whose shard is exhausted
+            ub_all, open_all = incumbent_exchange(ub, len(candidates))
+            if ub_all < ub:
+                ub = ub_all
+                candidates = [l for l in candidates if l.lb < ub - tol]
+            if open_all == 0:
+                break
+            if not candidates:
+                continue
+        elif not candidates:
             break
         cutoff = ub - tol
 
@@ -170,8 +182,6 @@ def branch_and_bound(
                 leaves.remove(node)
                 leaves.extend(children)
 
-        if incumbent_exchange is not None:
-            ub = min(ub, incumbent_exchange(ub))
         printer.update(leaves, ub, solves)
 
     printer.finalize(solves, ub)
