@@ -424,7 +424,8 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
     for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
     for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
 
-    int status = ST_MAXITER, it = 0;
+    int status = ST_MAXITER, it = 0, extra_done = 0;
+    const int extra = 1;
     double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
     double x0inf = vmaxabs(x0, nx);
     (void)hinf;
@@ -478,7 +479,13 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         double gap = fabs(pobj - dob);
         if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e pobj %.6e eta %.3e\n", it, tau, kap, mu, rcinf / tau, rdinf / tau, gap, pobj, -(fy + hz));
         if (rcinf / tau <= tol * (1 + winf + x0inf) && rdinf / tau <= tol * (1 + zinf) && gap <= tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
-            status = ST_OPTIMAL; break;
+            /* the test is met: take `extra` more iterations (convergence is superlinear here, so
+             * two implementations that cross the threshold one iteration apart still agree) */
+            status = ST_OPTIMAL;
+            if (extra_done >= extra || it == max_iter) break;
+            extra_done++;
+        } else if (status == ST_OPTIMAL) {
+            status = ST_MAXITER; /* an extra iteration left the tolerance again: keep iterating */
         }
         {   /* Farkas: E'y + C'z = rd - Pw, -(f'y + h'z) > 0 */
             double eta = -(fy + hz), cert = 0;
@@ -492,7 +499,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
 
         /* ---- factorisation ---- */
         for (int r = 0; r < M; r++) k->D[r] = k->act[r] ? k->z[r] / k->s[r] : 0.0;
-        if (factor(p, k, fix) != 0) { status = ST_NUMERICAL; break; }
+        if (factor(p, k, fix) != 0) { if (status != ST_OPTIMAL) status = ST_NUMERICAL; break; }
 
         /* ---- constant direction: rhs = (0; f; h) ---- */
         for (int t = 0; t < T; t++) { const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t]; for (int r = 0; r < m; r++) k->rhs_c[ro + r] = hh[r]; }
@@ -578,6 +585,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             }
         }
         if (!(tau > 0) || !(kap >= 0) || tau != tau) { status = ST_NUMERICAL; break; }
+        if (status == ST_OPTIMAL && it + 1 > max_iter) break;
     }
     *iters = it;
 

@@ -353,7 +353,7 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
     for (int i = lane; i < nx; i += WAVE) x0inf = fmax(x0inf, fabs(S.x0[i]));
     x0inf = wave_max(x0inf);
 
-    int status = HMPC_MAXITER, it = 0;
+    int status = HMPC_MAXITER, it = 0, extra_done = 0;
     for (it = 0; it <= p.max_iter; it++) {
         // ---------------- residuals ----------------
         double wPw = 0;
@@ -433,8 +433,13 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
         }
         if (rcinf / tau <= p.tol * (1 + winf / tau + x0inf) && rdinf / tau <= p.tol * (1 + zinf / tau) &&
             gap <= p.tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
+            // the test is met: one more iteration (convergence is superlinear here, so the CPU
+            // oracle and this kernel agree even if they cross the threshold an iteration apart)
             status = HMPC_OPTIMAL;
-            break;
+            if (extra_done >= 1 || it == p.max_iter) break;
+            extra_done++;
+        } else if (status == HMPC_OPTIMAL) {
+            status = HMPC_MAXITER; // the extra iteration left the tolerance again: keep iterating
         }
         if (eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
             status = HMPC_INFEASIBLE;
@@ -449,7 +454,7 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
             S.D[r] = row_active(p, S.fix, t, lr, term_on) ? S.z[r] / R.s[r] : 0.0;
         }
         __syncthreads();
-        if (factor(p, S, lane) != 0) { status = HMPC_NUMERICAL; break; }
+        if (factor(p, S, lane) != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
 
         // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
         for (int r = lane; r < M; r += WAVE) {
