@@ -36,7 +36,8 @@ def cpu_baseline(ctrl, x0, fix):
     """The CPU oracle (a float64 port of the same QP statement, oracle/hsde_qp.c) timed on the
     host cores of this box, on the same frontier.  A reported baseline, not the thing shipped."""
     from oracle.oracle_qp import OracleBatchedQP
-    cores = os.cpu_count() or 1
+    # the box gives each GPU a share of the host cores (16 per GPU); never oversubscribe beyond it
+    cores = min(len(os.sched_getaffinity(0)), 16)
     orc = OracleBatchedQP(ctrl.problem_data(), threads=cores)
     orc.solve_batch(x0, fix[:min(64, len(fix))])
     best = None

@@ -16,8 +16,7 @@
 
 #include "hmpc_device.h"
 
-extern "C" __global__ void hmpc_qp_kernel(const DevProb p, const double *x0g, int x0_stride, const int8_t *fixg, int B,
-                                          const DevOut out, double *rows_ws, double *trace);
+#include "hmpc_kernel.hip" // one translation unit: the kernel is launched from this file
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
@@ -176,6 +175,9 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     StageHost reg, last;
     build_stage(*q, q->F, q->G, q->h, q->nc, reg);
     build_stage(*q, q->F_Tm1, q->G_Tm1, q->h_Tm1, q->ncT, last);
+    p.mreg_magic = (unsigned)((0x100000000ULL + p.mreg - 1) / p.mreg);
+    p.nnz0 = (int)reg.rcol.size();
+    p.nng0 = (int)reg.grow.size();
 
     // cost Hessians, scaled so that their largest entry is one
     std::vector<double> P((size_t)nz * nz, 0.0), PT((size_t)nx * nx, 0.0);
@@ -227,13 +229,14 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
     const size_t lds_cu = 160 * 1024;
+    if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
     if (h->lds > lds_cu || (lds_max > 0 && h->lds > (size_t)lds_max)) {
         char msg[256];
         snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", h->lds, lds_max);
         hmpc_destroy(h);
         return fail(HMPC_ETOOBIG, msg);
     }
-    if (hipFuncSetAttribute((const void *)hmpc_qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+    if (hipFuncSetAttribute((const void *)hmpc_pick_kernel(p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
     }
@@ -247,8 +250,8 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
     }
     if (getenv("HMPC_TRACE")) {
-        (void)hipMalloc((void **)&h->trace, 2 * 64 * 8 * sizeof(double));
-        (void)hipMemset(h->trace, 0, 2 * 64 * 8 * sizeof(double));
+        (void)hipMalloc((void **)&h->trace, (2 * 64 * 8 + 16) * sizeof(double));
+        (void)hipMemset(h->trace, 0, (2 * 64 * 8 + 16) * sizeof(double));
     }
     *out = h;
     return HMPC_OK;
@@ -294,8 +297,8 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
     const int grid = B < h->max_grid ? B : h->max_grid;
     h->last_grid = grid;
-    hipLaunchKernelGGL(hmpc_qp_kernel, dim3(grid), dim3(64), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride, d_fix,
-                       B, o, h->rows_ws, h->trace);
+    hipLaunchKernelGGL(hmpc_pick_kernel(h->dp), dim3(grid), dim3(64), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
+                       d_fix, B, o, h->rows_ws, h->trace);
     HIPCHK(hipGetLastError());
     return HMPC_OK;
 }
@@ -349,7 +352,7 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     if (out->primal) HIPCHK(hipMemcpy(out->primal, h->d_primal, (size_t)B * p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
     if (out->dual) HIPCHK(hipMemcpy(out->dual, h->d_dual, (size_t)B * p.n_dual * sizeof(double), hipMemcpyDeviceToHost));
     if (h->trace) {
-        std::vector<double> tr(2 * 64 * 8);
+        std::vector<double> tr(2 * 64 * 8 + 16);
         (void)hipMemcpy(tr.data(), h->trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost);
         for (int ph = 0; ph < 2; ph++)
             for (int it = 0; it < 64; it++) {
@@ -358,6 +361,14 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
                 fprintf(stderr, "hip ph %d it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e eta %.3e cert %.3e\n", ph, it,
                         t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7]);
             }
+        const char *names[8] = {"residuals", "rows->D/e", "factor", "kkt_solve", "rhs aff/corr", "refine residual", "combine/step/update", "loop top"};
+        for (int ph = 0; ph < 2; ph++) {
+            double tot = 0;
+            for (int k = 0; k < 8; k++) tot += tr[2 * 64 * 8 + ph * 8 + k];
+            if (tot > 0)
+                for (int k = 0; k < 8; k++)
+                    fprintf(stderr, "hip stamps ph %d %-22s %12.0f cycles %5.1f%%\n", ph, names[k], tr[2 * 64 * 8 + ph * 8 + k], 100 * tr[2 * 64 * 8 + ph * 8 + k] / tot);
+        }
         (void)hipMemset(h->trace, 0, tr.size() * sizeof(double));
     }
     return HMPC_OK;

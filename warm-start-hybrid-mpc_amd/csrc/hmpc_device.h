@@ -23,6 +23,8 @@ struct SparseStage {
 
 struct DevProb {
     int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, Mpad, n, ne, nq, nr, nqT, n_primal, n_dual;
+    unsigned mreg_magic;                       // ceil(2^32 / mreg): r / mreg == umulhi(r, magic) for r < 2^16
+    int nnz0, nng0;                            // nonzeros / Gram terms of the regular stage (staged in LDS)
     SparseStage st[2];
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
     const int *ei, *ej;                        // lower-triangle entry -> (i, j)
@@ -41,16 +43,20 @@ struct DevOut {
 static inline size_t hmpc_lds_bytes(const DevProb &p)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
-    size_t d = 0;
-    d += n + (T + 1) * nx + T * nub;                                   // w lam nuf
-    d += 3 * M;                                                        // z D e
+    size_t d = 0, i = 0;
+    d += n + (T + 1) * nx + T * nub;                                      // w lam nuf
+    d += 3 * M;                                                           // z D e
     d += T * nu * nu + T * nu * nx + (T + 1) * nx * nx + T * nz + T * nu; // Minv Kg Pr mb mus
-    d += n + T * nx + n + n + (T + 1) * nx;                            // rd rdyn Pw g pv
-    d += 2 * (n + (T + 1) * nx + T * nub);                             // w1.. w2..
-    d += n + T * nx;                                                   // ed edyn
-    d += nz * nz + nz * nu + nx * nz + nx + nz;                        // Mm E PA q mv
-    d += nx;                                                           // x0
-    return d * sizeof(double) + T * nub * sizeof(int);
+    d += n + T * nx + n + n + (T + 1) * nx;                               // rd rdyn Pw g pv
+    d += 2 * (n + (T + 1) * nx + T * nub);                                // w1.. w2..
+    d += T * nx;                                                          // edyn
+    d += nz * nz + nz * nu + nx * nz + nx + nz;                           // Mm E PA q mv
+    d += nx;                                                              // x0
+    d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
+    d += p.mreg + 2 * (size_t)p.nnz0 + p.nng0;                            // h0 rval0 cval0 gval0
+    i += T * nub + 2 * (size_t)p.ne;                                      // fix ei ej
+    i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0 + (p.ne + 1) + p.nng0; // rptr0 rcol0 cptr0 crow0 gptr0 grow0
+    return d * sizeof(double) + i * sizeof(int);
 }
 
 #endif

@@ -1,11 +1,14 @@
 // hmpc_kernel.hip -- batched QP relaxations of hybrid-MPC branch-and-bound nodes on gfx950.
 //
 // One wavefront (64 lanes) owns one node's QP from start to finish:
-//   * the node-independent problem (A, B, cost Hessians, sparse row / column / Gram lists of the
-//     stage constraints) is read-only global data shared by every wave (L1/L2 resident, ~20 KB);
+//   * node-independent data that every sweep re-reads -- [A B], the cost Hessians, the scaled
+//     right-hand sides and the sparse row / column / Gram lists of the regular stage -- is staged
+//     into LDS once per workgroup; the lists of the last stage (which carries the terminal set and
+//     is ~10x larger) stay in global memory, read-only and L2 resident;
 //   * everything indexed by stage -- iterate, Newton directions, Riccati factor (gain, inverse
-//     input Hessian, cost-to-go per stage) -- and the three per-row vectors that other lanes must
-//     see (multipliers z, barrier weights D = z/s, scaled right-hand side e) live in LDS;
+//     input Hessian, cost-to-go per stage) -- and the per-row vectors that other lanes must see
+//     (multipliers z, barrier weights D = z/s, scaled right-hand side e) live in LDS, addressed
+//     through address-space-3 pointers so that every access is a ds_read / ds_write;
 //   * per-row temporaries that only their own lane touches (slack s, row residual, the constant
 //     direction, affine products) live in a per-workgroup slab of global memory, written and read
 //     coalesced (row r <-> lane r % 64), small enough to stay in L2 / Infinity Cache;
@@ -27,61 +30,124 @@
 #include "hmpc_device.h"
 
 #define WAVE 64
+#define DEV __device__ __forceinline__
 
-__device__ __forceinline__ double wave_sum(double v)
+// Diagnostic build only (-DHMPC_STAMPS): cycle stamps per phase of the interior-point loop,
+// accumulated for node 0 into the trace buffer.  No stamp executes in the shipped kernel.
+#ifdef HMPC_STAMPS
+#define STAMP(k) do { long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = clock64(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
+DEV double wave_sum(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-__device__ __forceinline__ double wave_max(double v)
+DEV double wave_max(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
     return v;
 }
-__device__ __forceinline__ double wave_min(double v)
+DEV double wave_min(double v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
     return v;
 }
 
+// LDS pointers carry their address space so that every access is a ds_read / ds_write (a generic
+// pointer would compile to flat_load: slower, and it ties up both memory counters).
+typedef __attribute__((address_space(3))) double ldsd;
+typedef __attribute__((address_space(3))) int ldsi;
+
+// Sparse lists of one stage type, resident in LDS (regular stage) or in global memory (last stage).
+template <class IP, class DP>
+struct Lists {
+    IP rptr, rcol, cptr, crow, gptr, grow;
+    DP rval, cval, gval, h;
+};
+typedef Lists<const ldsi *, const ldsd *> ListsL;
+typedef Lists<const int *, const double *> ListsG;
+
 struct Lds {
-    double *w, *lam, *nuf, *z, *D, *e;
-    double *Minv, *Kg, *Pr, *mb, *mus;
-    double *rd, *rdyn, *Pw, *g, *pv;
-    double *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
-    double *ed, *edyn;
-    double *Mm, *E, *PA, *q, *mv;
-    double *x0;
-    int *fix;
+    ldsd *w, *lam, *nuf, *z, *D, *e;
+    ldsd *Minv, *Kg, *Pr, *mb, *mus;
+    ldsd *rd, *rdyn, *Pw, *g, *pv;
+    ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
+    ldsd *edyn;
+    ldsd *Mm, *E, *PA, *q, *mv;
+    ldsd *x0;
+    ldsi *fix;
+    ldsd *AB, *P, *PT; // [A B] (nx x nz), scaled cost Hessians
+    ldsi *ei, *ej;     // lower-triangle entry -> (i, j)
+    ListsL L0;         // regular stage
+    ListsG L1;         // last stage
+};
+
+// Problem dimensions: compile-time for the instantiated shapes (index arithmetic folds to
+// immediates, inner loops unroll, divisions become multiplies), run-time for the generic kernel.
+template <int NX_, int NU_, int NUB_>
+struct Dims {
+    static DEV int nx(const DevProb &p) { return NX_ > 0 ? NX_ : p.nx; }
+    static DEV int nu(const DevProb &p) { return NU_ > 0 ? NU_ : p.nu; }
+    static DEV int nub(const DevProb &p) { return NU_ > 0 ? NUB_ : p.nub; }
+    static DEV int nuc(const DevProb &p) { return NU_ > 0 ? NU_ - NUB_ : p.nuc; }
+    static DEV int nz(const DevProb &p) { return NX_ > 0 ? NX_ + NU_ : p.nz; }
+    static DEV int ne(const DevProb &p) { return NX_ > 0 ? (NX_ + NU_) * (NX_ + NU_ + 1) / 2 : p.ne; }
 };
 
 struct Rows { // per-workgroup slab in global memory, row r <-> lane r % 64
-    double *s, *rc, *z1, *dz, *prod;
+    double *__restrict__ s, *__restrict__ rc, *__restrict__ z1, *__restrict__ dz, *__restrict__ prod;
 };
 
-__device__ __forceinline__ void row_decode(const DevProb &p, int r, int &t, int &lr)
+DEV void row_decode(const DevProb &p, int r, int &t, int &lr)
 {
-    t = r / p.mreg;
+    t = (int)__umulhi((unsigned)r, p.mreg_magic); // r / mreg, exact for r, mreg < 2^16
     if (t > p.T - 1) t = p.T - 1;
     lr = r - t * p.mreg;
 }
 
-__device__ __forceinline__ bool row_active(const DevProb &p, const int *fix, int t, int lr, int term_on)
+template <class D> DEV bool row_active(const DevProb &p, const ldsi *fix, int t, int lr, int term_on)
 {
-    const int mg = (t < p.T - 1) ? p.nc : p.ncL;
+    const int mg = (t < p.T - 1) ? p.nc : p.ncL, nub = D::nub(p);
     if (lr < mg) return term_on || t < p.T - 1 || lr < p.nc;
     int b = lr - mg;
-    if (b >= p.nub) b -= p.nub;
-    return fix[t * p.nub + b] < 0;
+    if (b >= nub) b -= nub;
+    return fix[t * nub + b] < 0;
 }
 
-__device__ __forceinline__ double AB(const DevProb &p, int l, int j)
-{ // [A B](l, j)
-    return j < p.nx ? p.A[l * p.nx + j] : p.B[l * p.nu + (j - p.nx)];
+template <class L> DEV double row_dot(const L &st, int lr, const ldsd *v)
+{
+    double a = 0;
+    for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * v[st.rcol[k]];
+    return a;
 }
+template <class L> DEV double col_dot(const L &st, int j, const ldsd *v)
+{
+    double a = 0;
+    for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * v[st.crow[k]];
+    return a;
+}
+template <class L> DEV double gram(const L &st, int e, const ldsd *D)
+{
+    double a = 0;
+    for (int k = st.gptr[e]; k < st.gptr[e + 1]; k++) a += st.gval[k] * D[st.grow[k]];
+    return a;
+}
+// C_t row / column products for any stage: the regular stage reads LDS, the last one global memory
+DEV double crow_dot(const DevProb &p, const Lds &S, int t, int lr, const ldsd *v)
+{
+    return t < p.T - 1 ? row_dot(S.L0, lr, v) : row_dot(S.L1, lr, v);
+}
+DEV double ccol_dot(const DevProb &p, const Lds &S, int t, int j, const ldsd *v)
+{
+    return t < p.T - 1 ? col_dot(S.L0, j, v) : col_dot(S.L1, j, v);
+}
+DEV double hrow(const DevProb &p, const Lds &S, int t, int lr) { return t < p.T - 1 ? S.L0.h[lr] : S.L1.h[lr]; }
 
 // ---------------------------------------------------------------------------------------------
 // Riccati factorisation of Phi_t = P + C_t' D C_t.  Per stage it leaves in LDS
@@ -91,75 +157,85 @@ __device__ __forceinline__ double AB(const DevProb &p, int l, int j)
 //   mb   = sum of the columns of M that belong to binaries fixed to one
 // with M = Phi_t + [A B]' Pr_{t+1} [A B] and the rows / columns of fixed binaries replaced by
 // identity (they are prescribed, not optimised).  Elimination runs on the symmetric matrix in
-// (u, x) order, one rank-one update per input and one barrier per update; carrying an identity
-// block through the same row operations yields the inverse and the gain without substitutions.
+// (u, x) order, one rank-one update and one barrier per free input (a fixed binary is decoupled
+// and its pivot is skipped); carrying an identity block through the same row operations yields
+// the inverse and the gain without any triangular substitution.
 // ---------------------------------------------------------------------------------------------
-__device__ int factor(const DevProb &p, const Lds &S, int lane)
+template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 {
-    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub;
-    for (int i = lane; i < nx * nx; i += WAVE) S.Pr[T * nx * nx + i] = p.PT[i];
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
+    for (int i = lane; i < nx * nx; i += WAVE) S.Pr[T * nx * nx + i] = S.PT[i];
     __syncthreads();
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
-        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
-        const double *Dt = S.D + t * p.mreg;
-        const double *Pn = S.Pr + (t + 1) * nx * nx;
-        // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
-        for (int e = lane; e < p.ne; e += WAVE) {
-            const int i = p.ei[e], j = p.ej[e];
-            double a = p.P[i * nz + j];
-            for (int k = st.gptr[e]; k < st.gptr[e + 1]; k++) a += st.gval[k] * Dt[st.grow[k]];
+        const ldsd *Dt = S.D + t * p.mreg;
+        const ldsd *Pn = S.Pr + (t + 1) * nx * nx;
+        const ldsi *fx = S.fix + t * nub;
+        int nfixed = 0;
+        for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
+        // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B] ; E = identity block on the inputs
+        for (int e = lane; e < ne; e += WAVE) {
+            const int i = S.ei[e], j = S.ej[e];
+            const double a = S.P[i * nz + j] + (t < T - 1 ? gram(S.L0, e, Dt) : gram(S.L1, e, Dt));
             S.Mm[i * nz + j] = a;
             S.Mm[j * nz + i] = a;
         }
         for (int e = lane; e < nx * nz; e += WAVE) {
             const int i = e / nz, j = e - i * nz;
             double a = 0;
-            for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * AB(p, l, j);
+            for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * S.AB[l * nz + j];
             S.PA[e] = a;
-        }
-        __syncthreads();
-        for (int e = lane; e < p.ne; e += WAVE) {
-            const int i = p.ei[e], j = p.ej[e];
-            double a = 0;
-            for (int l = 0; l < nx; l++) a += AB(p, l, i) * S.PA[l * nz + j];
-            a += S.Mm[i * nz + j];
-            S.Mm[i * nz + j] = a;
-            S.Mm[j * nz + i] = a;
-        }
-        __syncthreads();
-        // columns of binaries fixed to one (needed by the constant direction)
-        for (int i = lane; i < nz; i += WAVE) {
-            double a = 0;
-            for (int b = 0; b < nub; b++)
-                if (S.fix[t * nub + b] == 1) a += S.Mm[i * nz + nx + nuc + b];
-            S.mb[t * nz + i] = a;
-        }
-        __syncthreads();
-        // prescribed inputs: identity row / column ; E = identity block on the inputs
-        for (int e = lane; e < nz * nz; e += WAVE) {
-            const int i = e / nz, j = e - i * nz;
-            const bool fi = i >= nx + nuc && S.fix[t * nub + (i - nx - nuc)] >= 0;
-            const bool fj = j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0;
-            if (fi || fj) S.Mm[e] = (i == j) ? 1.0 : 0.0;
         }
         for (int e = lane; e < nz * nu; e += WAVE) {
             const int i = e / nu, c = e - i * nu;
             S.E[e] = (i == nx + c) ? 1.0 : 0.0;
         }
         __syncthreads();
-        // elimination of the inputs, pivot order u_0 .. u_{nu-1}
+        for (int e = lane; e < ne; e += WAVE) {
+            const int i = S.ei[e], j = S.ej[e];
+            double a = S.Mm[i * nz + j];
+            for (int l = 0; l < nx; l++) a += S.AB[l * nz + i] * S.PA[l * nz + j];
+            S.Mm[i * nz + j] = a;
+            S.Mm[j * nz + i] = a;
+        }
+        __syncthreads();
+        if (nfixed) {
+            // columns of binaries fixed to one (needed by the constant direction), then
+            // prescribed inputs become identity rows / columns
+            for (int i = lane; i < nz; i += WAVE) {
+                double a = 0;
+                for (int b = 0; b < nub; b++)
+                    if (fx[b] == 1) a += S.Mm[i * nz + nx + nuc + b];
+                S.mb[t * nz + i] = a;
+            }
+            __syncthreads();
+            for (int e = lane; e < nz * nz; e += WAVE) {
+                const int i = e / nz, j = e - i * nz;
+                const bool fi = i >= nx + nuc && fx[i - nx - nuc] >= 0;
+                const bool fj = j >= nx + nuc && fx[j - nx - nuc] >= 0;
+                if (fi || fj) S.Mm[e] = (i == j) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+        } else {
+            for (int i = lane; i < nz; i += WAVE) S.mb[t * nz + i] = 0.0;
+        }
+        // elimination of the free inputs, pivot order u_0 .. u_{nu-1}
         for (int j = 0; j < nu; j++) {
+            if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot
+                if (lane == 0) S.mv[j] = 1.0;
+                continue;
+            }
             const int pj = nx + j;
             const double d = S.Mm[pj * nz + pj];
             if (!(d > 0.0)) bad = 1;
-            const double rinv = 1.0 / d;
-            // rows still to be reduced: inputs j+1.. and all states.  Each lane owns one
-            // (row, column) pair of the trailing block or of the carried identity block.
-            const int nrem = nx + (nu - 1 - j);            // rows: states first, then later inputs
-            const int ncols = nrem + nu;                   // trailing columns + E columns
-            // In place: an entry is read and written by its own lane only; the pivot row and
-            // column, which every lane reads, are not part of the trailing block.
+            double rinv = __builtin_amdgcn_rcp(d);
+            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
+            // rows still to be reduced: all states and the inputs after j.  In place: an entry is
+            // read and written by its own lane only; the pivot row and column, which every lane
+            // reads, are not part of the trailing block.  Only columns c <= j of the carried
+            // identity block are nonzero in the pivot row (it is unit lower triangular).
+            const int nrem = nx + (nu - 1 - j);
+            const int ncols = nrem + j + 1;
             for (int e = lane; e < nrem * ncols; e += WAVE) {
                 const int a = e / ncols, bcol = e - a * ncols;
                 const int i = a < nx ? a : pj + 1 + (a - nx);
@@ -172,8 +248,10 @@ __device__ int factor(const DevProb &p, const Lds &S, int lane)
                     S.E[i * nu + c] -= mij * S.E[pj * nu + c];
                 }
             }
+            if (lane == 0) S.mv[j] = rinv; // reciprocal pivots for the inverse below
             __syncthreads();
         }
+        __syncthreads();
         // After the sweep: Mm[x][x] = Schur complement, E[x][:] = -M_xu M_uu^{-1} = -Kg',
         // E[u][:] = unit-lower inverse factor, pivots on the diagonal of Mm[u][u].
         for (int e = lane; e < nx * nx; e += WAVE) {
@@ -188,33 +266,31 @@ __device__ int factor(const DevProb &p, const Lds &S, int lane)
             const int i = e / nu, j = e - i * nu;
             double a = 0;
             for (int l = (i > j ? i : j); l < nu; l++)
-                a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] / S.Mm[(nx + l) * nz + nx + l];
+                a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] * S.mv[l];
             S.Minv[t * nu * nu + e] = a;
         }
         __syncthreads();
     }
-    return __any(bad) ? -1 : 0;
+    return bad ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // One KKT solve  K d = rhs  by a backward / forward Riccati sweep.
-//   rhs_d  : gs * gsrc (n entries; gsrc may be null)       stage gradients
-//   x_0    : x0 if usex0 else 0                               prescribed initial state
-//   cdyn   : cs * csrc (T*nx; csrc may be null)               dynamics offsets
+//   rhs_d  : gs * gsrc (n entries; gsrc may be null; gsrc may alias S.g)   stage gradients
+//   x_0    : x0 if usex0 else 0                                            prescribed initial state
+//   cdyn   : cs * csrc (T*nx; csrc may be null)                            dynamics offsets
 //   useb   : fixed binaries take their value v (constant direction) or 0
 //   S.e    : D .* rhs_c on entry ; the multiplier step dz on exit
 // ---------------------------------------------------------------------------------------------
-__device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double *gsrc, double gs, bool usex0,
-                          const double *csrc, double cs, bool useb, double *dw, double *dlam, double *dnuf)
+template <class D>
+DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+                   const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf)
 {
-    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub;
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     // g = rhs_d + C' e  (column lists)
     for (int o = lane; o < T * nz; o += WAVE) {
         const int t = o / nz, j = o - t * nz;
-        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
-        const double *et = S.e + t * p.mreg;
-        double a = gsrc ? gs * gsrc[o] : 0.0;
-        for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * et[st.crow[k]];
+        const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot(p, S, t, j, S.e + t * p.mreg);
         S.g[o] = a;
     }
     for (int j = lane; j < nx; j += WAVE) {
@@ -225,17 +301,20 @@ __device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double
     __syncthreads();
     // backward sweep
     for (int t = T - 1; t >= 0; t--) {
-        const double *Pn = S.Pr + (t + 1) * nx * nx;
-        for (int i = lane; i < nx; i += WAVE) {
-            double a = S.pv[(t + 1) * nx + i];
-            if (csrc)
+        const ldsd *qv = S.pv + (t + 1) * nx;
+        if (csrc) {
+            const ldsd *Pn = S.Pr + (t + 1) * nx * nx;
+            for (int i = lane; i < nx; i += WAVE) {
+                double a = S.pv[(t + 1) * nx + i];
                 for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * cs * csrc[t * nx + l];
-            S.q[i] = a;
+                S.q[i] = a;
+            }
+            __syncthreads();
+            qv = S.q;
         }
-        __syncthreads();
         for (int j = lane; j < nz; j += WAVE) {
             double a = -S.g[t * nz + j];
-            for (int l = 0; l < nx; l++) a += AB(p, l, j) * S.q[l];
+            for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * qv[l];
             if (useb) a += S.mb[t * nz + j];
             if (j >= nx + nuc) {
                 const int f = S.fix[t * nub + (j - nx - nuc)];
@@ -256,7 +335,7 @@ __device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double
     for (int i = lane; i < nx; i += WAVE) dw[i] = usex0 ? S.x0[i] : 0.0;
     __syncthreads();
     for (int t = 0; t < T; t++) {
-        const double *x = dw + t * nz;
+        const ldsd *x = dw + t * nz;
         for (int i = lane; i < nu; i += WAVE) {
             double a = 0;
             for (int l = 0; l < nx; l++) a += S.Kg[t * nu * nx + i * nx + l] * x[l];
@@ -266,7 +345,7 @@ __device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double
         __syncthreads();
         for (int i = lane; i < nx; i += WAVE) {
             double a = csrc ? cs * csrc[t * nx + i] : 0.0;
-            for (int l = 0; l < nz; l++) a += AB(p, i, l) * dw[t * nz + l];
+            for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * dw[t * nz + l];
             dw[(t + 1) * nz + i] = a;
         }
         __syncthreads();
@@ -279,25 +358,25 @@ __device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double
         dlam[o] = -a;
     }
     for (int r = lane; r < p.M; r += WAVE) {
-        int t, lr;
-        row_decode(p, r, t, lr);
-        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
-        double a = 0;
-        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * dw[t * nz + st.rcol[k]];
-        S.e[r] = S.D[r] * a - S.e[r];
+        const double d = S.D[r];
+        if (d != 0.0) { // inactive rows keep e = 0
+            int t, lr;
+            row_decode(p, r, t, lr);
+            S.e[r] = d * crow_dot(p, S, t, lr, dw + t * nz) - S.e[r];
+        }
     }
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
+    const bool own_g = gsrc && gsrc != S.g; // a refinement call passes its residual in S.g (zero there)
     for (int o = lane; o < T * nub; o += WAVE) {
         const int t = o / nub, b = o - t * nub;
         double a = 0;
         if (S.fix[o] >= 0) {
-            const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
             const int c = nx + nuc + b;
-            a = gsrc ? gs * gsrc[t * nz + c] : 0.0;
-            for (int j = 0; j < nz; j++) a -= p.P[c * nz + j] * dw[t * nz + j];
-            for (int k = st.cptr[c]; k < st.cptr[c + 1]; k++) a -= st.cval[k] * S.e[t * p.mreg + st.crow[k]];
-            for (int l = 0; l < nx; l++) a += p.B[l * nu + (c - nx)] * dlam[(t + 1) * nx + l];
+            a = own_g ? gs * gsrc[t * nz + c] : 0.0;
+            for (int j = 0; j < nz; j++) a -= S.P[c * nz + j] * dw[t * nz + j];
+            a -= ccol_dot(p, S, t, c, S.e + t * p.mreg);
+            for (int l = 0; l < nx; l++) a += S.AB[l * nz + c] * dlam[(t + 1) * nx + l];
         }
         dnuf[o] = a;
     }
@@ -305,38 +384,44 @@ __device__ void kkt_solve(const DevProb &p, const Lds &S, int lane, const double
 }
 
 // f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
-__device__ double lin_obj(const DevProb &p, const Lds &S, int lane, const double *lam, const double *nuf, const double *zrow)
+template <class D>
+DEV double lin_obj(const DevProb &p, const Lds &S, int lane, const ldsd *lam, const ldsd *nuf, const ldsd *zrow)
 {
     double a = 0;
-    for (int j = lane; j < p.nx; j += WAVE) a += S.x0[j] * lam[j];
-    for (int o = lane; o < p.T * p.nub; o += WAVE)
+    for (int j = lane; j < D::nx(p); j += WAVE) a += S.x0[j] * lam[j];
+    for (int o = lane; o < p.T * D::nub(p); o += WAVE)
         if (S.fix[o] == 1) a += nuf[o];
     for (int r = lane; r < p.M; r += WAVE) {
-        int t, lr;
-        row_decode(p, r, t, lr);
-        a += p.st[t < p.T - 1 ? 0 : 1].h[lr] * zrow[r];
+        const double v = zrow[r];
+        if (v != 0.0) {
+            int t, lr;
+            row_decode(p, r, t, lr);
+            a += hrow(p, S, t, lr) * v;
+        }
     }
     return wave_sum(a);
 }
 
-__device__ void set_prescribed(const DevProb &p, const Lds &S, int lane, double tau)
+template <class D> DEV void set_prescribed(const DevProb &p, const Lds &S, int lane, double tau)
 {
-    for (int i = lane; i < p.nx; i += WAVE) S.w[i] = S.x0[i] * tau;
-    for (int o = lane; o < p.T * p.nub; o += WAVE)
-        if (S.fix[o] >= 0) S.w[(o / p.nub) * p.nz + p.nx + p.nuc + (o % p.nub)] = S.fix[o] * tau;
+    const int nub = D::nub(p);
+    for (int i = lane; i < D::nx(p); i += WAVE) S.w[i] = S.x0[i] * tau;
+    for (int o = lane; o < p.T * nub; o += WAVE)
+        if (S.fix[o] >= 0) S.w[(o / nub) * D::nz(p) + D::nx(p) + D::nuc(p) + (o % nub)] = S.fix[o] * tau;
 }
 
 // One interior-point solve of the node with / without the terminal-set rows.
-// Returns status; tau, iteration count and the largest terminal-row value through references.
-__device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int term_on, int &iters,
-                         double &tau_out, double *trace)
+// Returns status; tau and the iteration count through references.
+template <class D>
+DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int term_on, int &iters, double &tau_out,
+                  double *trace)
 {
-    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nuc = p.nuc, nub = p.nub, M = p.M, n = p.n;
+    const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     int mact = 0;
     for (int r = lane; r < M; r += WAVE) {
         int t, lr;
         row_decode(p, r, t, lr);
-        const bool on = row_active(p, S.fix, t, lr, term_on);
+        const bool on = row_active<D>(p, S.fix, t, lr, term_on);
         mact += on;
         R.s[r] = 1.0;
         S.z[r] = on ? 1.0 : 0.0;
@@ -347,20 +432,24 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
     for (int i = lane; i < T * nub; i += WAVE) S.nuf[i] = 0.0;
     double tau = 1.0, kap = 1.0;
     __syncthreads();
-    set_prescribed(p, S, lane, tau);
+    set_prescribed<D>(p, S, lane, tau);
     __syncthreads();
     double x0inf = 0;
     for (int i = lane; i < nx; i += WAVE) x0inf = fmax(x0inf, fabs(S.x0[i]));
     x0inf = wave_max(x0inf);
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
+#ifdef HMPC_STAMPS
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
     for (it = 0; it <= p.max_iter; it++) {
+        STAMP(7);
         // ---------------- residuals ----------------
         double wPw = 0;
         for (int o = lane; o < n; o += WAVE) {
             const int t = o / nz < T ? o / nz : T;
             const int i = o - t * nz, dim = t < T ? nz : nx;
-            const double *PP = t < T ? p.P : p.PT;
+            const ldsd *PP = t < T ? S.P : S.PT;
             double a = 0;
             for (int j = 0; j < dim; j++) a += PP[i * dim + j] * S.w[t * nz + j];
             S.Pw[o] = a;
@@ -375,11 +464,10 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
             if (t == T) {
                 a = S.lam[T * nx + j];
             } else {
-                const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
                 if (j < nx) a += S.lam[t * nx + j];
-                for (int l = 0; l < nx; l++) a -= AB(p, l, j) * S.lam[(t + 1) * nx + l];
+                for (int l = 0; l < nx; l++) a -= S.AB[l * nz + j] * S.lam[(t + 1) * nx + l];
                 if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
-                for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * S.z[t * p.mreg + st.crow[k]];
+                a += ccol_dot(p, S, t, j, S.z + t * p.mreg);
             }
             const double v = S.Pw[o] + a;
             S.rd[o] = v;
@@ -387,31 +475,29 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
             certinf = fmax(certinf, fabs(a));
             winf = fmax(winf, fabs(S.w[o]));
         }
+        double rcinf = 0;
         for (int o = lane; o < T * nx; o += WAVE) {
             const int t = o / nx, i = o - t * nx;
             double a = S.w[(t + 1) * nz + i];
-            for (int l = 0; l < nz; l++) a -= AB(p, i, l) * S.w[t * nz + l];
+            for (int l = 0; l < nz; l++) a -= S.AB[i * nz + l] * S.w[t * nz + l];
             S.rdyn[o] = a;
+            rcinf = fmax(rcinf, fabs(a));
         }
-        double rcinf = 0, hz = 0, sz = 0, zinf = 0;
+        double hz = 0, sz = 0, zinf = 0;
         for (int r = lane; r < M; r += WAVE) {
             int t, lr;
             row_decode(p, r, t, lr);
-            const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
             double a = 0;
-            if (row_active(p, S.fix, t, lr, term_on)) {
-                const double zr = S.z[r], sr = R.s[r];
-                a = sr - st.h[lr] * tau;
-                for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * S.w[t * nz + st.rcol[k]];
-                hz += st.h[lr] * zr;
+            if (row_active<D>(p, S.fix, t, lr, term_on)) {
+                const double zr = S.z[r], sr = R.s[r], hh = hrow(p, S, t, lr);
+                a = sr - hh * tau + crow_dot(p, S, t, lr, S.w + t * nz);
+                hz += hh * zr;
                 sz += sr * zr;
                 zinf = fmax(zinf, zr);
             }
             R.rc[r] = a;
             rcinf = fmax(rcinf, fabs(a));
         }
-        __syncthreads(); // rdyn visible
-        for (int o = lane; o < T * nx; o += WAVE) rcinf = fmax(rcinf, fabs(S.rdyn[o]));
         for (int o = lane; o < (T + 1) * nx; o += WAVE) yinf = fmax(yinf, fabs(S.lam[o]));
         for (int o = lane; o < T * nub; o += WAVE) {
             yinf = fmax(yinf, fabs(S.nuf[o]));
@@ -423,6 +509,7 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
         fy = wave_sum(fy); hz = wave_sum(hz); sz = wave_sum(sz);
         const double rg = wPw / tau + fy + hz + kap;
         const double mu = (sz + tau * kap) / (mact + 1);
+        STAMP(0);
 
         // ---------------- termination ----------------
         const double pobj = 0.5 * wPw / (tau * tau), dob = -0.5 * wPw / (tau * tau) - (fy + hz) / tau;
@@ -449,26 +536,26 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
 
         // ---------------- factorisation ----------------
         for (int r = lane; r < M; r += WAVE) {
+            const double zr = S.z[r]; // zero on inactive rows
+            const double d = zr != 0.0 ? zr / R.s[r] : 0.0;
             int t, lr;
             row_decode(p, r, t, lr);
-            S.D[r] = row_active(p, S.fix, t, lr, term_on) ? S.z[r] / R.s[r] : 0.0;
+            S.D[r] = d;
+            S.e[r] = d * hrow(p, S, t, lr); // right-hand side of the constant direction
         }
         __syncthreads();
-        if (factor(p, S, lane) != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
+        STAMP(1);
+        if (factor<D>(p, S, lane) != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
+        STAMP(2);
 
         // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-        for (int r = lane; r < M; r += WAVE) {
-            int t, lr;
-            row_decode(p, r, t, lr);
-            S.e[r] = S.D[r] * p.st[t < T - 1 ? 0 : 1].h[lr];
-        }
-        __syncthreads();
-        kkt_solve(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1);
+        kkt_solve<D>(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1);
+        STAMP(3);
         double g1 = 0;
         for (int o = lane; o < n; o += WAVE) g1 += S.Pw[o] * S.w1[o];
         g1 = wave_sum(g1) * 2.0 / tau;
         for (int r = lane; r < M; r += WAVE) R.z1[r] = S.e[r];
-        const double fyhz1 = lin_obj(p, S, lane, S.lam1, S.nuf1, S.e);
+        const double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
         const double den = kap / tau + wPw / (tau * tau) - g1 - fyhz1;
 
         double dtau_a = 0, dkap_a = 0, sigma = 0;
@@ -478,18 +565,22 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
             __syncthreads();
             for (int r = lane; r < M; r += WAVE) {
                 double v = 0;
-                if (S.D[r] != 0.0) { // active row
-                    const double dsr = R.s[r] * S.z[r] + (pass ? R.prod[r] - sigma * mu : 0.0);
-                    v = S.D[r] * (-lin * R.rc[r] + dsr / S.z[r]);
+                const double d = S.D[r];
+                if (d != 0.0) { // active row
+                    const double zr = S.z[r];
+                    const double dsr = R.s[r] * zr + (pass ? R.prod[r] - sigma * mu : 0.0);
+                    v = d * (-lin * R.rc[r] + dsr / zr);
                 }
                 S.e[r] = v;
             }
             __syncthreads();
-            kkt_solve(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2);
+            STAMP(4);
+            kkt_solve<D>(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2);
+            STAMP(3);
             double g2 = 0;
             for (int o = lane; o < n; o += WAVE) g2 += S.Pw[o] * S.w2[o];
             g2 = wave_sum(g2) * 2.0 / tau;
-            const double fyhz2 = lin_obj(p, S, lane, S.lam2, S.nuf2, S.e);
+            const double fyhz2 = lin_obj<D>(p, S, lane, S.lam2, S.nuf2, S.e);
             const double dtau = (lin * rg - dkap_rhs / tau + g2 + fyhz2) / den;
             const double dkap = -(dkap_rhs + kap * dtau) / tau;
             // combined direction d = v2 + dtau v1
@@ -508,43 +599,45 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
                 for (int o = lane; o < n; o += WAVE) {
                     const int t = o / nz < T ? o / nz : T;
                     const int j = o - t * nz, dim = t < T ? nz : nx;
-                    const double *PP = t < T ? p.P : p.PT;
+                    const ldsd *PP = t < T ? S.P : S.PT;
                     double a = -lin * S.rd[o];
                     for (int l = 0; l < dim; l++) a -= PP[j * dim + l] * S.w2[t * nz + l];
                     if (t == T) {
                         a -= S.lam2[T * nx + j];
                     } else {
-                        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
                         if (j < nx) a -= S.lam2[t * nx + j];
-                        for (int l = 0; l < nx; l++) a += AB(p, l, j) * S.lam2[(t + 1) * nx + l];
-                        for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a -= st.cval[k] * S.e[t * p.mreg + st.crow[k]];
+                        for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * S.lam2[(t + 1) * nx + l];
+                        a -= ccol_dot(p, S, t, j, S.e + t * p.mreg);
                         if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a = 0.0;
                         if (t == 0 && j < nx) a = 0.0;
                     }
-                    S.ed[o] = a;
+                    S.g[o] = a;
                 }
                 for (int o = lane; o < T * nx; o += WAVE) {
                     const int t = o / nx, i = o - t * nx;
                     double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
-                    for (int l = 0; l < nz; l++) a += AB(p, i, l) * S.w2[t * nz + l];
+                    for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * S.w2[t * nz + l];
                     S.edyn[o] = a;
                 }
                 __syncthreads();
                 for (int r = lane; r < M; r += WAVE) {
                     double v = 0;
-                    if (S.D[r] != 0.0) {
+                    const double d = S.D[r];
+                    if (d != 0.0) {
                         int t, lr;
                         row_decode(p, r, t, lr);
-                        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
-                        const double dsr = R.s[r] * S.z[r] + R.prod[r] - sigma * mu;
-                        double a = -lin * R.rc[r] + dsr / S.z[r] + dtau * st.h[lr] + S.e[r] * R.s[r] / S.z[r];
-                        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a -= st.rval[k] * S.w2[t * nz + st.rcol[k]];
-                        v = S.D[r] * a;
+                        const double zr = S.z[r], sr = R.s[r];
+                        const double dsr = sr * zr + R.prod[r] - sigma * mu;
+                        const double a = -lin * R.rc[r] + dsr / zr + dtau * hrow(p, S, t, lr) + S.e[r] * sr / zr -
+                                         crow_dot(p, S, t, lr, S.w2 + t * nz);
+                        v = d * a;
                     }
                     S.e[r] = v;
                 }
                 __syncthreads();
-                kkt_solve(p, S, lane, S.ed, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1);
+                STAMP(5);
+                kkt_solve<D>(p, S, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1);
+                STAMP(3);
                 for (int o = lane; o < n; o += WAVE) S.w2[o] += S.w1[o];
                 for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += S.lam1[o];
                 for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += S.nuf1[o];
@@ -585,35 +678,38 @@ __device__ int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane
                 tau += alpha * dtau;
                 kap += alpha * dkap;
                 __syncthreads();
-                set_prescribed(p, S, lane, tau);
+                set_prescribed<D>(p, S, lane, tau);
                 __syncthreads();
             }
         }
+        STAMP(6);
         if (!(tau > 0) || !(kap >= 0)) { status = HMPC_NUMERICAL; break; }
     }
+#ifdef HMPC_STAMPS
+    if (trace && lane == 0)
+        for (int k = 0; k < 8; k++) trace[2 * 64 * 8 + (term_on ? 8 : 0) + k] = (double)tacc[k];
+#endif
     iters = it;
     tau_out = tau;
     return status;
 }
 
 // Largest value of (scaled terminal row) - h at the current (optimal) iterate.
-__device__ double terminal_violation(const DevProb &p, const Lds &S, int lane, double tau)
+template <class D> DEV double terminal_violation(const DevProb &p, const Lds &S, int lane, double tau)
 {
-    const SparseStage &st = p.st[1];
     double tv = -1e300;
     for (int lr = p.nc + lane; lr < p.ncL; lr += WAVE) {
-        double a = -st.h[lr] * tau;
-        for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * S.w[(p.T - 1) * p.nz + st.rcol[k]];
+        const double a = row_dot(S.L1, lr, S.w + (p.T - 1) * D::nz(p)) - S.L1.h[lr] * tau;
         tv = fmax(tv, a / tau);
     }
     return wave_max(tv);
 }
 
 // Output record in the reference's conventions (subproblem_solution.py:68-168).
-__device__ void write_record(const DevProb &p, const Lds &S, const Rows &R, int lane, int status, double tau,
-                             int qp, const DevOut &out)
+template <class D>
+DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, double tau, int qp, const DevOut &out)
 {
-    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nub = p.nub, M = p.M;
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M;
     const int nmu = (T - 1) * p.nc + p.ncL;
     const bool inf = status == HMPC_INFEASIBLE;
     double scale;
@@ -639,12 +735,12 @@ __device__ void write_record(const DevProb &p, const Lds &S, const Rows &R, int 
     for (int r = lane; r < M; r += WAVE) {
         int t, lr;
         row_decode(p, r, t, lr);
-        const SparseStage &st = p.st[t < T - 1 ? 0 : 1];
         const int mg = t < T - 1 ? p.nc : p.ncL;
         if (lr < mg) {
-            const double v = S.z[r] * scale * st.scale[lr];
+            const double sc = p.st[t < T - 1 ? 0 : 1].scale[lr];
+            const double v = S.z[r] * scale * sc;
             if (dual) dual[o_mu + t * p.nc + lr] = v;
-            farkas -= (st.h[lr] / st.scale[lr]) * v;
+            farkas -= (hrow(p, S, t, lr) / sc) * v;
         }
     }
     for (int o = lane; o < T * nub; o += WAVE) {
@@ -674,7 +770,7 @@ __device__ void write_record(const DevProb &p, const Lds &S, const Rows &R, int 
             for (int o = lane; o < T * nu; o += WAVE) prim[(T + 1) * nx + o] = S.w[(o / nu) * nz + nx + (o % nu)] / tau;
         }
         for (int o = lane; o < T * p.nq + p.nqT; o += WAVE) {
-            const int t = o / p.nq < T ? o / p.nq : T;
+            const int t = (p.nq > 0 && o / p.nq < T) ? o / p.nq : T;
             const int r = o - t * p.nq;
             const double *QQ = t < T ? p.Q : p.QT;
             double a = 0;
@@ -701,17 +797,20 @@ __device__ void write_record(const DevProb &p, const Lds &S, const Rows &R, int 
     }
 }
 
-extern "C" __global__ void __launch_bounds__(WAVE)
+template <int NX_, int NU_, int NUB_>
+__global__ void __launch_bounds__(WAVE)
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef Dims<NX_, NU_, NUB_> D;
     const int lane = threadIdx.x;
-    const int nx = p.nx, nu = p.nu, nz = p.nz, T = p.T, nub = p.nub, M = p.M, n = p.n;
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M, n = T * nz + nx, ne = D::ne(p);
     Lds S;
     {
-        double *q = reinterpret_cast<double *>(smem);
-        auto take = [&](int cnt) { double *r = q; q += cnt; return r; };
+        // the carve below must mirror hmpc_lds_bytes() in hmpc_device.h
+        ldsd *q = (ldsd *)smem;
+        auto take = [&](int cnt) { ldsd *r = q; q += cnt; return r; };
         S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
         S.z = take(M); S.D = take(M); S.e = take(M);
         S.Minv = take(T * nu * nu); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nx * nx);
@@ -719,10 +818,34 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.rd = take(n); S.rdyn = take(T * nx); S.Pw = take(n); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         S.w2 = take(n); S.lam2 = take((T + 1) * nx); S.nuf2 = take(T * nub);
-        S.ed = take(n); S.edyn = take(T * nx);
+        S.edyn = take(T * nx);
         S.Mm = take(nz * nz); S.E = take(nz * nu); S.PA = take(nx * nz); S.q = take(nx); S.mv = take(nz);
         S.x0 = take(nx);
-        S.fix = reinterpret_cast<int *>(q);
+        S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
+        ldsd *h0 = take(p.mreg), *rval0 = take(p.nnz0), *cval0 = take(p.nnz0), *gval0 = take(p.nng0);
+        ldsi *qi = (ldsi *)q;
+        auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
+        S.fix = takei(T * nub);
+        S.ei = takei(ne); S.ej = takei(ne);
+        ldsi *rptr0 = takei(p.mreg + 1), *rcol0 = takei(p.nnz0), *cptr0 = takei(nz + 1), *crow0 = takei(p.nnz0);
+        ldsi *gptr0 = takei(ne + 1), *grow0 = takei(p.nng0);
+        // stage the node-independent data
+        const SparseStage &g0 = p.st[0], &g1 = p.st[1];
+        for (int i = lane; i < nx * nz; i += WAVE) {
+            const int l = i / nz, j = i - l * nz;
+            S.AB[i] = j < nx ? p.A[l * nx + j] : p.B[l * nu + (j - nx)];
+        }
+        for (int i = lane; i < nz * nz; i += WAVE) S.P[i] = p.P[i];
+        for (int i = lane; i < nx * nx; i += WAVE) S.PT[i] = p.PT[i];
+        for (int i = lane; i < p.mreg; i += WAVE) h0[i] = g0.h[i];
+        for (int i = lane; i < p.nnz0; i += WAVE) { rval0[i] = g0.rval[i]; cval0[i] = g0.cval[i]; rcol0[i] = g0.rcol[i]; crow0[i] = g0.crow[i]; }
+        for (int i = lane; i < p.nng0; i += WAVE) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
+        for (int i = lane; i < p.mreg + 1; i += WAVE) rptr0[i] = g0.rptr[i];
+        for (int i = lane; i < nz + 1; i += WAVE) cptr0[i] = g0.cptr[i];
+        for (int i = lane; i < ne + 1; i += WAVE) gptr0[i] = g0.gptr[i];
+        for (int i = lane; i < ne; i += WAVE) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
+        S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
+        S.L1 = ListsG{g1.rptr, g1.rcol, g1.cptr, g1.crow, g1.gptr, g1.grow, g1.rval, g1.cval, g1.gval, g1.h};
     }
     Rows R;
     {
@@ -734,22 +857,36 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int o = lane; o < T * nub; o += WAVE) S.fix[o] = fixg[(size_t)qp * T * nub + o];
         for (int i = lane; i < nx; i += WAVE) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
         __syncthreads();
-        int it1 = 0, it2 = 0, status;
+        int it1 = 0, it2 = 0, status = HMPC_MAXITER;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
-        if (p.ncL > p.nc && p.lazy) {
-            // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for
-            // the node and carries no terminal multipliers; an optimum that satisfies the masked
-            // rows strictly is the node's optimum.  Otherwise solve again with every row.
-            status = ipm_solve(p, S, R, lane, 0, it1, tau, tr);
-            bool done = status == HMPC_INFEASIBLE;
-            if (status == HMPC_OPTIMAL) done = terminal_violation(p, S, lane, tau) < 0.0;
-            if (!done) status = ipm_solve(p, S, R, lane, 1, it2, tau, tr ? tr + 64 * 8 : nullptr);
-        } else {
-            status = ipm_solve(p, S, R, lane, 1, it1, tau, tr);
+        // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
+        // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
+        // is the node's optimum.  Otherwise solve again with every row.
+        const int first = (p.ncL > p.nc && p.lazy) ? 0 : 1;
+        for (int term_on = first; term_on < 2; term_on++) {
+            int its = 0;
+            status = ipm_solve<D>(p, S, R, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
+            if (term_on == 0) it1 = its; else it2 = its;
+            if (term_on == 0) {
+                bool done = status == HMPC_INFEASIBLE;
+                if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
+                if (done) break;
+            }
         }
         __syncthreads();
-        write_record(p, S, R, lane, status, tau, qp, out);
+        write_record<D>(p, S, lane, status, tau, qp, out);
         if (lane == 0 && out.iters) out.iters[qp] = it1 + it2;
     }
+}
+
+// Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
+// nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries) and the
+// generic run-time-sized kernel for everything else.
+typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *);
+static hmpc_kernel_t hmpc_pick_kernel(const DevProb &p)
+{
+    if (p.nx == 4 && p.nu == 7 && p.nub == 4) return hmpc_qp_kernel<4, 7, 4>;
+    if (p.nx == 4 && p.nu == 4 && p.nub == 2) return hmpc_qp_kernel<4, 4, 2>;
+    return hmpc_qp_kernel<0, 0, 0>;
 }
