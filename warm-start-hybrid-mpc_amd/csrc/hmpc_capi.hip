@@ -158,9 +158,10 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     if (hipSetDevice(dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "hipSetDevice failed"); }
 
     DevProb &p = h->dp;
+    const int nx = q->nx, nu = q->nu, nz = q->nx + q->nu;
     p.nx = q->nx; p.nu = q->nu; p.nub = q->nub; p.nuc = q->nu - q->nub; p.nz = q->nx + q->nu; p.T = q->T;
-    p.nc = q->nc; p.ncL = q->ncT; p.mreg = q->nc + 2 * q->nub; p.mlast = q->ncT + 2 * q->nub;
-    p.M = (q->T - 1) * p.mreg + p.mlast; p.Mpad = (p.M + 63) / 64 * 64;
+    p.nc = q->nc; p.ncL = q->ncT; p.nT = q->ncT - q->nc; p.mreg = q->nc + 2 * q->nub;
+    p.Toff = q->T * p.mreg; p.M = p.Toff + p.nT; p.Mpad = (p.M + 63) / 64 * 64;
     p.n = q->T * p.nz + q->nx; p.ne = p.nz * (p.nz + 1) / 2;
     p.nq = q->nq; p.nr = q->nr; p.nqT = q->nqT;
     p.n_primal = (q->T + 1) * q->nx + q->T * q->nu;
@@ -171,13 +172,31 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     p.lazy = opt ? opt->lazy_terminal : 1;
     p.refine = opt ? opt->refine : 1;
 
-    const int nx = p.nx, nu = p.nu, nz = p.nz;
-    StageHost reg, last;
+    StageHost reg;
     build_stage(*q, q->F, q->G, q->h, q->nc, reg);
-    build_stage(*q, q->F_Tm1, q->G_Tm1, q->h_Tm1, q->ncT, last);
     p.mreg_magic = (unsigned)((0x100000000ULL + p.mreg - 1) / p.mreg);
     p.nnz0 = (int)reg.rcol.size();
     p.nng0 = (int)reg.grow.size();
+    // The first nc rows of [F_Tm1 G_Tm1 | h_Tm1] must be the stage rows [F G | h] (controller.py:85-87):
+    // the last stage then shares the stage lists and only the terminal-set rows are kept apart.
+    for (int r = 0; r < q->nc; r++) {
+        bool same = q->h_Tm1[r] == q->h[r];
+        for (int j = 0; j < nx && same; j++) same = q->F_Tm1[r * nx + j] == q->F[r * nx + j];
+        for (int j = 0; j < nu && same; j++) same = q->G_Tm1[r * nu + j] == q->G[r * nu + j];
+        if (!same) { hmpc_destroy(h); return fail(HMPC_EINVAL, "the first nc rows of F_Tm1, G_Tm1, h_Tm1 must equal F, G, h"); }
+    }
+    std::vector<double> Ct((size_t)(p.nT > 0 ? p.nT : 1) * nz, 0.0), ht(p.nT > 0 ? p.nT : 1, 0.0), sct(p.nT > 0 ? p.nT : 1, 1.0);
+    for (int k = 0; k < p.nT; k++) {
+        const int r = q->nc + k;
+        double n2 = 0;
+        for (int j = 0; j < nx; j++) n2 += q->F_Tm1[r * nx + j] * q->F_Tm1[r * nx + j];
+        for (int j = 0; j < nu; j++) n2 += q->G_Tm1[r * nu + j] * q->G_Tm1[r * nu + j];
+        const double sc = n2 > 0 ? 1.0 / std::sqrt(n2) : 1.0;
+        sct[k] = sc;
+        for (int j = 0; j < nx; j++) Ct[(size_t)k * nz + j] = sc * q->F_Tm1[r * nx + j];
+        for (int j = 0; j < nu; j++) Ct[(size_t)k * nz + nx + j] = sc * q->G_Tm1[r * nu + j];
+        ht[k] = sc * q->h_Tm1[r];
+    }
 
     // cost Hessians, scaled so that their largest entry is one
     std::vector<double> P((size_t)nz * nz, 0.0), PT((size_t)nx * nx, 0.0);
@@ -209,8 +228,10 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
     int rc = HMPC_OK;
     do {
-        if ((rc = upload_stage(h, reg, p.st[0]))) break;
-        if ((rc = upload_stage(h, last, p.st[1]))) break;
+        if ((rc = upload_stage(h, reg, p.reg))) break;
+        if ((rc = upload(h, Ct, &p.Ct))) break;
+        if ((rc = upload(h, ht, &p.ht))) break;
+        if ((rc = upload(h, sct, &p.sct))) break;
         if ((rc = upload(h, vec(q->A, (size_t)nx * nx), &p.A))) break;
         if ((rc = upload(h, vec(q->B, (size_t)nx * nu), &p.B))) break;
         if ((rc = upload(h, P, &p.P))) break;
@@ -250,8 +271,8 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
     }
     if (getenv("HMPC_TRACE")) {
-        (void)hipMalloc((void **)&h->trace, (2 * 64 * 8 + 16) * sizeof(double));
-        (void)hipMemset(h->trace, 0, (2 * 64 * 8 + 16) * sizeof(double));
+        (void)hipMalloc((void **)&h->trace, (2 * 64 * 8 + 32) * sizeof(double));
+        (void)hipMemset(h->trace, 0, (2 * 64 * 8 + 32) * sizeof(double));
     }
     *out = h;
     return HMPC_OK;
@@ -352,7 +373,7 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     if (out->primal) HIPCHK(hipMemcpy(out->primal, h->d_primal, (size_t)B * p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
     if (out->dual) HIPCHK(hipMemcpy(out->dual, h->d_dual, (size_t)B * p.n_dual * sizeof(double), hipMemcpyDeviceToHost));
     if (h->trace) {
-        std::vector<double> tr(2 * 64 * 8 + 16);
+        std::vector<double> tr(2 * 64 * 8 + 32);
         (void)hipMemcpy(tr.data(), h->trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost);
         for (int ph = 0; ph < 2; ph++)
             for (int it = 0; it < 64; it++) {
@@ -369,6 +390,9 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
                 for (int k = 0; k < 8; k++)
                     fprintf(stderr, "hip stamps ph %d %-22s %12.0f cycles %5.1f%%\n", ph, names[k], tr[2 * 64 * 8 + ph * 8 + k], 100 * tr[2 * 64 * 8 + ph * 8 + k] / tot);
         }
+        const char *fn[11] = {"F gram+PA", "F assemble col", "F prescribe", "F eliminate", "F writeback+sync", "F Minv", "S g=C'e", "S backward", "S Minv*mu", "S forward", "S lam,dz,dnuf"};
+        for (int k = 0; k < 11; k++)
+            if (tr[2 * 64 * 8 + 16 + k] > 0) fprintf(stderr, "hip fine   %-22s %12.0f cycles\n", fn[k], tr[2 * 64 * 8 + 16 + k]);
         (void)hipMemset(h->trace, 0, tr.size() * sizeof(double));
     }
     return HMPC_OK;

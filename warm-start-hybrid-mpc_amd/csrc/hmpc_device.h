@@ -6,9 +6,8 @@
 
 #include "hmpc.h"
 
-// Constraint rows of one stage type (0: stages 0..T-2, 1: stage T-1 with the terminal set),
-// bound rows of the binaries appended ([F G] rows, then -ub <= -lb, then ub <= ubmax),
-// general rows scaled to unit 2-norm.  All arrays are device pointers.
+// Constraint rows of a stage: [F G] rows scaled to unit 2-norm, then the bound rows of the binaries
+// (-ub <= -lb, then ub <= ubmax).  All arrays are device pointers.
 struct SparseStage {
     int m, mg;                 // rows with / without the bound rows
     const int *rptr, *rcol;    // rows (CSR):    C w        row-parallel
@@ -22,10 +21,11 @@ struct SparseStage {
 };
 
 struct DevProb {
-    int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, Mpad, n, ne, nq, nr, nqT, n_primal, n_dual;
+    int nx, nu, nub, nuc, nz, T, nc, ncL, nT, mreg, Toff, M, Mpad, n, ne, nq, nr, nqT, n_primal, n_dual;
     unsigned mreg_magic;                       // ceil(2^32 / mreg): r / mreg == umulhi(r, magic) for r < 2^16
     int nnz0, nng0;                            // nonzeros / Gram terms of the regular stage (staged in LDS)
-    SparseStage st[2];
+    SparseStage reg;                           // stage rows: [F G] (nc) then the bounds of the binaries (2 nub)
+    const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
     const int *ei, *ej;                        // lower-triangle entry -> (i, j)
     double cs;                                 // cost scale
@@ -46,7 +46,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
     size_t d = 0, i = 0;
     d += n + (T + 1) * nx + T * nub;                                      // w lam nuf
     d += 3 * M;                                                           // z D e
-    d += T * nu * nu + T * nu * nx + (T + 1) * nx * nx + T * nz + T * nu; // Minv Kg Pr mb mus
+    d += T * nu * nu + T * nu * nx + (T + 1) * nx * nx + T * nz + 2 * T * nu; // Minv Kg Pr mb mus ru
     d += n + T * nx + n + n + (T + 1) * nx;                               // rd rdyn Pw g pv
     d += 2 * (n + (T + 1) * nx + T * nub);                                // w1.. w2..
     d += T * nx;                                                          // edyn

@@ -3,8 +3,9 @@
 // One wavefront (64 lanes) owns one node's QP from start to finish:
 //   * node-independent data that every sweep re-reads -- [A B], the cost Hessians, the scaled
 //     right-hand sides and the sparse row / column / Gram lists of the regular stage -- is staged
-//     into LDS once per workgroup; the lists of the last stage (which carries the terminal set and
-//     is ~10x larger) stay in global memory, read-only and L2 resident;
+//     into LDS once per workgroup; every stage uses them.  The terminal-set rows (a dense block that
+//     exists only at the last stage and is masked in most solves) are kept apart, appended after all
+//     stage rows, in global memory (read-only, L2 resident), and touched only when they are active;
 //   * everything indexed by stage -- iterate, Newton directions, Riccati factor (gain, inverse
 //     input Hessian, cost-to-go per stage) -- and the per-row vectors that other lanes must see
 //     (multipliers z, barrier weights D = z/s, scaled right-hand side e) live in LDS, addressed
@@ -36,8 +37,17 @@
 // accumulated for node 0 into the trace buffer.  No stamp executes in the shipped kernel.
 #ifdef HMPC_STAMPS
 #define STAMP(k) do { long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = clock64(); } while (0)
+#define FSTAMP(k) do { long long now_ = clock64(); facc[k] += now_ - flast; flast = clock64(); } while (0)
+#define FSTAMP_DECL long long flast = clock64()
+static __device__ long long facc_dump[16];
+#define FSTAMP_ARGS , long long *facc
+#define FSTAMP_PASS , facc
 #else
 #define STAMP(k) do { } while (0)
+#define FSTAMP(k) do { } while (0)
+#define FSTAMP_DECL do { } while (0)
+#define FSTAMP_ARGS
+#define FSTAMP_PASS
 #endif
 
 DEV double wave_sum(double v)
@@ -59,6 +69,15 @@ DEV double wave_min(double v)
     return v;
 }
 
+// Broadcast of one lane's double to the whole wave through two v_readlane (the result is wave
+// uniform and lives in SGPRs: no LDS round trip).  src must be wave uniform.
+DEV double bcast(double v, int src)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
 // LDS pointers carry their address space so that every access is a ds_read / ds_write (a generic
 // pointer would compile to flat_load: slower, and it ties up both memory counters).
 typedef __attribute__((address_space(3))) double ldsd;
@@ -71,11 +90,10 @@ struct Lists {
     DP rval, cval, gval, h;
 };
 typedef Lists<const ldsi *, const ldsd *> ListsL;
-typedef Lists<const int *, const double *> ListsG;
 
 struct Lds {
     ldsd *w, *lam, *nuf, *z, *D, *e;
-    ldsd *Minv, *Kg, *Pr, *mb, *mus;
+    ldsd *Minv, *Kg, *Pr, *mb, *mus, *ru;
     ldsd *rd, *rdyn, *Pw, *g, *pv;
     ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
     ldsd *edyn;
@@ -84,14 +102,15 @@ struct Lds {
     ldsi *fix;
     ldsd *AB, *P, *PT; // [A B] (nx x nz), scaled cost Hessians
     ldsi *ei, *ej;     // lower-triangle entry -> (i, j)
-    ListsL L0;         // regular stage
-    ListsG L1;         // last stage
+    ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
+    int term_on;       // terminal-set rows active in the current solve
 };
 
 // Problem dimensions: compile-time for the instantiated shapes (index arithmetic folds to
 // immediates, inner loops unroll, divisions become multiplies), run-time for the generic kernel.
 template <int NX_, int NU_, int NUB_>
 struct Dims {
+    static constexpr int kNX = NX_, kNU = NU_, kNUB = NUB_;
     static DEV int nx(const DevProb &p) { return NX_ > 0 ? NX_ : p.nx; }
     static DEV int nu(const DevProb &p) { return NU_ > 0 ? NU_ : p.nu; }
     static DEV int nub(const DevProb &p) { return NU_ > 0 ? NUB_ : p.nub; }
@@ -100,54 +119,143 @@ struct Dims {
     static DEV int ne(const DevProb &p) { return NX_ > 0 ? (NX_ + NU_) * (NX_ + NU_ + 1) / 2 : p.ne; }
 };
 
-struct Rows { // per-workgroup slab in global memory, row r <-> lane r % 64
-    double *__restrict__ s, *__restrict__ rc, *__restrict__ z1, *__restrict__ dz, *__restrict__ prod;
+// Per-row values that only the owning lane touches (row r <-> lane r % 64, slot k = r / 64):
+// slack s, row residual rc, constant-direction step z1, combined step dz, affine product prod.
+// RS > 0: RS slots per lane, kept in registers (every loop over slots is fully unrolled so the
+// arrays are statically indexed).  RS == 0: run-time number of slots, kept in a per-workgroup slab
+// of global memory (coalesced, L2 resident) -- the generic kernel.
+template <int RS>
+struct Rows {
+    double s_[RS], rc_[RS], z1_[RS], dz_[RS], prod_[RS];
+    DEV double &s(int k, int) { return s_[k]; }
+    DEV double &rc(int k, int) { return rc_[k]; }
+    DEV double &z1(int k, int) { return z1_[k]; }
+    DEV double &dz(int k, int) { return dz_[k]; }
+    DEV double &prod(int k, int) { return prod_[k]; }
+    DEV void bind(double *, int) {}
 };
+template <>
+struct Rows<0> {
+    double *__restrict__ s_, *__restrict__ rc_, *__restrict__ z1_, *__restrict__ dz_, *__restrict__ prod_;
+    DEV double &s(int, int r) { return s_[r]; }
+    DEV double &rc(int, int r) { return rc_[r]; }
+    DEV double &z1(int, int r) { return z1_[r]; }
+    DEV double &dz(int, int r) { return dz_[r]; }
+    DEV double &prod(int, int r) { return prod_[r]; }
+    DEV void bind(double *base, int Mpad) { s_ = base; rc_ = base + Mpad; z1_ = base + 2 * Mpad; dz_ = base + 3 * Mpad; prod_ = base + 4 * Mpad; }
+};
+// loop over the rows of this lane: slot k, row r
+#define ROWS_BEGIN(k, r)                                   \
+    _Pragma("unroll") for (int k = 0; k < nslot; k++) {   \
+        const int r = k * WAVE + lane;                     \
+        if (r < M) {
+#define ROWS_END }}
 
+// Row r -> (stage t, local row lr).  Rows [0, T*mreg) are the stage rows, mreg per stage; the
+// terminal-set rows follow (r >= Toff) and belong to the last stage with lr = mreg + k.
 DEV void row_decode(const DevProb &p, int r, int &t, int &lr)
 {
-    t = (int)__umulhi((unsigned)r, p.mreg_magic); // r / mreg, exact for r, mreg < 2^16
-    if (t > p.T - 1) t = p.T - 1;
-    lr = r - t * p.mreg;
+    if (r >= p.Toff) {
+        t = p.T - 1;
+        lr = p.mreg + (r - p.Toff);
+    } else {
+        t = (int)__umulhi((unsigned)r, p.mreg_magic); // r / mreg, exact for r, mreg < 2^16
+        lr = r - t * p.mreg;
+    }
 }
 
 template <class D> DEV bool row_active(const DevProb &p, const ldsi *fix, int t, int lr, int term_on)
 {
-    const int mg = (t < p.T - 1) ? p.nc : p.ncL, nub = D::nub(p);
-    if (lr < mg) return term_on || t < p.T - 1 || lr < p.nc;
-    int b = lr - mg;
+    const int nub = D::nub(p);
+    if (lr >= p.mreg) return term_on;
+    if (lr < p.nc) return true;
+    int b = lr - p.nc;
     if (b >= nub) b -= nub;
     return fix[t * nub + b] < 0;
 }
 
+// Sparse dot products.  Each term is two dependent loads (index, then the indexed value); the
+// terms are independent, so the loops are unrolled four wide to keep four chains in flight.
+template <class IP, class DP> DEV double list_dot(IP idx, DP val, int k0, int k1, const ldsd *v)
+{
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {
+        const int i0 = idx[k], i1 = idx[k + 1], i2 = idx[k + 2], i3 = idx[k + 3];
+        const double c0 = val[k], c1 = val[k + 1], c2 = val[k + 2], c3 = val[k + 3];
+        a0 += c0 * v[i0];
+        a1 += c1 * v[i1];
+        a2 += c2 * v[i2];
+        a3 += c3 * v[i3];
+    }
+    if (k + 2 <= k1) {
+        const int i0 = idx[k], i1 = idx[k + 1];
+        const double c0 = val[k], c1 = val[k + 1];
+        a0 += c0 * v[i0];
+        a1 += c1 * v[i1];
+        k += 2;
+    }
+    if (k < k1) a2 += val[k] * v[idx[k]];
+    return (a0 + a1) + (a2 + a3);
+}
 template <class L> DEV double row_dot(const L &st, int lr, const ldsd *v)
 {
-    double a = 0;
-    for (int k = st.rptr[lr]; k < st.rptr[lr + 1]; k++) a += st.rval[k] * v[st.rcol[k]];
-    return a;
+    return list_dot(st.rcol, st.rval, st.rptr[lr], st.rptr[lr + 1], v);
 }
 template <class L> DEV double col_dot(const L &st, int j, const ldsd *v)
 {
-    double a = 0;
-    for (int k = st.cptr[j]; k < st.cptr[j + 1]; k++) a += st.cval[k] * v[st.crow[k]];
-    return a;
+    return list_dot(st.crow, st.cval, st.cptr[j], st.cptr[j + 1], v);
 }
 template <class L> DEV double gram(const L &st, int e, const ldsd *D)
 {
+    return list_dot(st.grow, st.gval, st.gptr[e], st.gptr[e + 1], D);
+}
+// C_t row / column products.  `base` is a row-indexed LDS vector (z, e, ...); `v` a stage vector.
+template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, const ldsd *v)
+{
+    if (lr < p.mreg) return row_dot(S.L0, lr, v);
+    const int nz = D::nz(p);
+    const double *c = p.Ct + (size_t)(lr - p.mreg) * nz; // dense terminal row
     double a = 0;
-    for (int k = st.gptr[e]; k < st.gptr[e + 1]; k++) a += st.gval[k] * D[st.grow[k]];
+    for (int j = 0; j < nz; j++) a += c[j] * v[j];
     return a;
 }
-// C_t row / column products for any stage: the regular stage reads LDS, the last one global memory
-DEV double crow_dot(const DevProb &p, const Lds &S, int t, int lr, const ldsd *v)
+template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, int j, const ldsd *base)
 {
-    return t < p.T - 1 ? row_dot(S.L0, lr, v) : row_dot(S.L1, lr, v);
+    double a = col_dot(S.L0, j, base + t * p.mreg);
+    if (S.term_on && t == p.T - 1) {
+        const int nz = D::nz(p);
+        const ldsd *vt = base + p.Toff;
+        double a0 = 0, a1 = 0;
+        int k = 0;
+        for (; k + 2 <= p.nT; k += 2) {
+            a0 += p.Ct[(size_t)k * nz + j] * vt[k];
+            a1 += p.Ct[(size_t)(k + 1) * nz + j] * vt[k + 1];
+        }
+        if (k < p.nT) a0 += p.Ct[(size_t)k * nz + j] * vt[k];
+        a += a0 + a1;
+    }
+    return a;
 }
-DEV double ccol_dot(const DevProb &p, const Lds &S, int t, int j, const ldsd *v)
+DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? S.L0.h[lr] : p.ht[lr - p.mreg]; }
+// (C' D C)(i, j) of stage t: Gram lists of the stage rows, plus the dense terminal block if active
+template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, int e, int i, int j)
 {
-    return t < p.T - 1 ? col_dot(S.L0, j, v) : col_dot(S.L1, j, v);
+    double a = gram(S.L0, e, S.D + t * p.mreg);
+    if (S.term_on && t == p.T - 1) {
+        const int nz = D::nz(p);
+        const ldsd *Dt = S.D + p.Toff;
+        double a0 = 0, a1 = 0;
+        int k = 0;
+        for (; k + 2 <= p.nT; k += 2) {
+            a0 += p.Ct[(size_t)k * nz + i] * p.Ct[(size_t)k * nz + j] * Dt[k];
+            a1 += p.Ct[(size_t)(k + 1) * nz + i] * p.Ct[(size_t)(k + 1) * nz + j] * Dt[k + 1];
+        }
+        if (k < p.nT) a0 += p.Ct[(size_t)k * nz + i] * p.Ct[(size_t)k * nz + j] * Dt[k];
+        a += a0 + a1;
+    }
+    return a;
 }
-DEV double hrow(const DevProb &p, const Lds &S, int t, int lr) { return t < p.T - 1 ? S.L0.h[lr] : S.L1.h[lr]; }
 
 // ---------------------------------------------------------------------------------------------
 // Riccati factorisation of Phi_t = P + C_t' D C_t.  Per stage it leaves in LDS
@@ -168,7 +276,6 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
     __syncthreads();
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Dt = S.D + t * p.mreg;
         const ldsd *Pn = S.Pr + (t + 1) * nx * nx;
         const ldsi *fx = S.fix + t * nub;
         int nfixed = 0;
@@ -176,7 +283,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B] ; E = identity block on the inputs
         for (int e = lane; e < ne; e += WAVE) {
             const int i = S.ei[e], j = S.ej[e];
-            const double a = S.P[i * nz + j] + (t < T - 1 ? gram(S.L0, e, Dt) : gram(S.L1, e, Dt));
+            const double a = S.P[i * nz + j] + gram_entry<D>(p, S, t, e, i, j);
             S.Mm[i * nz + j] = a;
             S.Mm[j * nz + i] = a;
         }
@@ -275,6 +382,141 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Same factorisation for the compile-time shapes, with the stage matrix in registers: lane c < nz
+// owns column c of M, lanes nz .. nz+nu-1 own the columns of the carried identity block.  A pivot
+// step broadcasts the pivot column with v_readlane (wave-uniform SGPR values) and every lane
+// updates its own column: no LDS traffic and no barrier inside the elimination.  Per stage there
+// are two barriers: after the Gram / P[A B] phase and after the results are written back.
+// ---------------------------------------------------------------------------------------------
+template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
+{
+    FSTAMP_DECL;
+    constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
+    const int T = p.T;
+    for (int i = lane; i < NX * NX; i += WAVE) S.Pr[T * NX * NX + i] = S.PT[i];
+    __syncthreads();
+    int bad = 0;
+    for (int t = T - 1; t >= 0; t--) {
+        const ldsd *Pn = S.Pr + (t + 1) * NX * NX;
+        const ldsi *fx = S.fix + t * NUB;
+        // phase 1 (LDS): M = P + C' D C by Gram lists ; PA = Pn [A B]
+        for (int e = lane; e < NE; e += WAVE) {
+            const int i = S.ei[e], j = S.ej[e];
+            const double a = S.P[i * NZ + j] + gram_entry<D>(p, S, t, e, i, j);
+            S.Mm[i * NZ + j] = a;
+            S.Mm[j * NZ + i] = a;
+        }
+        for (int e = lane; e < NX * NZ; e += WAVE) {
+            const int i = e / NZ, j = e - i * NZ;
+            double a = 0;
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += Pn[i * NX + l] * S.AB[l * NZ + j];
+            S.PA[e] = a;
+        }
+        __syncthreads();
+        FSTAMP(0);
+        // phase 2 (registers): assemble the column, prescribe, eliminate
+        double col[NZ];
+        if (lane < NZ) {
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                double a = S.Mm[i * NZ + lane];
+#pragma unroll
+                for (int l = 0; l < NX; l++) a += S.AB[l * NZ + i] * S.PA[l * NZ + lane];
+                col[i] = a;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NZ; i++) col[i] = (i - NX == lane - NZ) ? 1.0 : 0.0;
+        }
+        FSTAMP(1);
+        int nfixed = 0;
+#pragma unroll
+        for (int b = 0; b < NUB; b++) nfixed += fx[b] >= 0;
+        if (nfixed) {
+            // columns of binaries fixed to one (for the constant direction), before prescribing
+            double mbv[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) mbv[i] = 0.0;
+#pragma unroll
+            for (int b = 0; b < NUB; b++)
+                if (fx[b] == 1) {
+#pragma unroll
+                    for (int i = 0; i < NZ; i++) mbv[i] += bcast(col[i], NX + NUC + b);
+                }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < NZ; i++) S.mb[t * NZ + i] = mbv[i];
+            }
+#pragma unroll
+            for (int b = 0; b < NUB; b++)
+                if (fx[b] >= 0) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int cb = NX + NUC + b;
+                    if (lane < NZ) {
+#pragma unroll
+                        for (int i = 0; i < NZ; i++)
+                            col[i] = (lane == cb) ? (i == cb ? 1.0 : 0.0) : (i == cb ? 0.0 : col[i]);
+                    }
+                }
+        } else if (lane < NZ) {
+            S.mb[t * NZ + lane] = 0.0;
+        }
+        FSTAMP(2);
+        double dinv[NU];
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            if (j >= NUC && fx[j - NUC] >= 0) { // decoupled unit pivot
+                dinv[j] = 1.0;
+                continue;
+            }
+            constexpr int dummy = 0; (void)dummy;
+            const int pj = NX + j;
+            const double d = bcast(col[pj], pj);
+            if (!(d > 0.0)) bad = 1;
+            double rinv = __builtin_amdgcn_rcp(d);
+            rinv = rinv * (2.0 - d * rinv);
+            dinv[j] = rinv;
+            const double cpj = col[pj];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                if (i < NX || i > pj) { // rows still to be reduced
+                    const double m = bcast(col[i], pj) * rinv;
+                    col[i] -= m * cpj;
+                }
+            }
+        }
+        FSTAMP(3);
+        // write back: Schur complement (state lanes), gain and unit-lower inverse factor (E lanes)
+        if (lane < NX) {
+#pragma unroll
+            for (int i = 0; i < NX; i++) S.Pr[t * NX * NX + i * NX + lane] = col[i];
+        } else if (lane >= NZ && lane < NZ + NU) {
+            const int c = lane - NZ;
+#pragma unroll
+            for (int x = 0; x < NX; x++) S.Kg[t * NU * NX + c * NX + x] = -col[x];
+#pragma unroll
+            for (int l = 0; l < NU; l++) S.E[(NX + l) * NU + c] = col[NX + l];
+        }
+        __syncthreads();
+        FSTAMP(4);
+        // phase 3: M_uu^{-1} = E_u' diag(1/pivot) E_u ; overlaps with the next stage's phase 1
+        for (int e = lane; e < NU * NU; e += WAVE) {
+            const int i = e / NU, j = e - i * NU;
+            const int lo = i > j ? i : j;
+            double a = 0;
+#pragma unroll
+            for (int l = 0; l < NU; l++)
+                if (l >= lo) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * dinv[l];
+            S.Minv[t * NU * NU + e] = a;
+        }
+        FSTAMP(5);
+    }
+    __syncthreads();
+    return bad ? -1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
 // One KKT solve  K d = rhs  by a backward / forward Riccati sweep.
 //   rhs_d  : gs * gsrc (n entries; gsrc may be null; gsrc may alias S.g)   stage gradients
 //   x_0    : x0 if usex0 else 0                                            prescribed initial state
@@ -290,7 +532,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     // g = rhs_d + C' e  (column lists)
     for (int o = lane; o < T * nz; o += WAVE) {
         const int t = o / nz, j = o - t * nz;
-        const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot(p, S, t, j, S.e + t * p.mreg);
+        const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
         S.g[o] = a;
     }
     for (int j = lane; j < nx; j += WAVE) {
@@ -362,7 +604,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
         if (d != 0.0) { // inactive rows keep e = 0
             int t, lr;
             row_decode(p, r, t, lr);
-            S.e[r] = d * crow_dot(p, S, t, lr, dw + t * nz) - S.e[r];
+            S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * nz) - S.e[r];
         }
     }
     __syncthreads();
@@ -375,12 +617,152 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
             const int c = nx + nuc + b;
             a = own_g ? gs * gsrc[t * nz + c] : 0.0;
             for (int j = 0; j < nz; j++) a -= S.P[c * nz + j] * dw[t * nz + j];
-            a -= ccol_dot(p, S, t, c, S.e + t * p.mreg);
+            a -= ccol_dot<D>(p, S, t, c, S.e);
             for (int l = 0; l < nx; l++) a += S.AB[l * nz + c] * dlam[(t + 1) * nx + l];
         }
         dnuf[o] = a;
     }
     __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same solve for the compile-time shapes, with the two recursions in registers: lane j holds
+// component j of the stage vector, the handful of values every lane needs (cost-to-go gradient,
+// inputs, state) travel by v_readlane, and everything that does not depend on the recursion
+// (C' e, M_uu^{-1} m_u, gains) is prepared in parallel phases before the sweep.  No barrier and no
+// LDS round trip on the critical path of a stage.
+// ---------------------------------------------------------------------------------------------
+template <class D>
+DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+                       const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
+{
+    constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
+    const int T = p.T;
+    FSTAMP_DECL;
+    // S.g <- (mb if useb) - (rhs_d + C' e): the part of the stage gradient the recursion does not touch
+    for (int o = lane; o < T * NZ; o += WAVE) {
+        const int t = o / NZ, j = o - t * NZ;
+        const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
+        S.g[o] = (useb ? S.mb[o] : 0.0) - a;
+    }
+    double pvr = 0.0; // lane i < NX: p_{t+1}[i]
+    if (lane < NX) {
+        pvr = -(gsrc ? gs * gsrc[T * NZ + lane] : 0.0);
+        S.pv[T * NX + lane] = pvr;
+    }
+    __syncthreads();
+    FSTAMP(6);
+    {   // backward sweep
+        double ABcol[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
+        for (int t = T - 1; t >= 0; t--) {
+            const double mpre = lane < NZ ? S.g[t * NZ + lane] : 0.0;
+            int f = -1;
+            if (lane >= NX + NUC && lane < NZ) f = S.fix[t * NUB + lane - NX - NUC];
+            double kg[NU];
+#pragma unroll
+            for (int l = 0; l < NU; l++) kg[l] = lane < NX ? S.Kg[t * NU * NX + l * NX + lane] : 0.0;
+            double qv = pvr;
+            if (csrc && lane < NX) {
+#pragma unroll
+                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * NX * NX + lane * NX + l] * cs * csrc[t * NX + l];
+            }
+            double m = mpre;
+#pragma unroll
+            for (int l = 0; l < NX; l++) m += ABcol[l] * bcast(qv, l);
+            if (f >= 0) m = (useb && f == 1) ? -1.0 : 0.0;
+            if (lane >= NX && lane < NZ) S.mus[t * NU + lane - NX] = m;
+            double pn = m;
+#pragma unroll
+            for (int l = 0; l < NU; l++) pn -= kg[l] * bcast(m, NX + l);
+            pvr = pn;
+            if (lane < NX) S.pv[t * NX + lane] = pn;
+        }
+    }
+    __syncthreads();
+    FSTAMP(7);
+    // M_uu^{-1} m_u for every stage at once
+    for (int o = lane; o < T * NU; o += WAVE) {
+        const int t = o / NU, i = o - t * NU;
+        double a = 0;
+#pragma unroll
+        for (int l = 0; l < NU; l++) a += S.Minv[t * NU * NU + i * NU + l] * S.mus[t * NU + l];
+        S.ru[o] = a;
+    }
+    __syncthreads();
+    FSTAMP(8);
+    {   // forward sweep
+        double ABrow[NZ];
+#pragma unroll
+        for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
+        double xr = (lane < NX && usex0) ? S.x0[lane] : 0.0;
+        for (int t = 0; t < T; t++) {
+            double kgr[NX];
+#pragma unroll
+            for (int l = 0; l < NX; l++) kgr[l] = lane < NU ? S.Kg[t * NU * NX + lane * NX + l] : 0.0;
+            const double ru = lane < NU ? S.ru[t * NU + lane] : 0.0;
+            const double cdy = (csrc && lane < NX) ? cs * csrc[t * NX + lane] : 0.0;
+            double u = -ru, xn = cdy;
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                const double xl = bcast(xr, l);
+                u -= kgr[l] * xl;
+                xn += ABrow[l] * xl;
+            }
+#pragma unroll
+            for (int l = 0; l < NU; l++) xn += ABrow[NX + l] * bcast(u, l);
+            if (lane < NX) dw[t * NZ + lane] = xr;
+            if (lane < NU) dw[t * NZ + NX + lane] = u;
+            xr = xn;
+        }
+        if (lane < NX) dw[T * NZ + lane] = xr;
+    }
+    __syncthreads();
+    FSTAMP(9);
+    // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
+    for (int o = lane; o < (T + 1) * NX; o += WAVE) {
+        const int t = o / NX, i = o - t * NX;
+        double a = S.pv[o];
+#pragma unroll
+        for (int l = 0; l < NX; l++) a += S.Pr[t * NX * NX + i * NX + l] * dw[t * NZ + l];
+        dlam[o] = -a;
+    }
+    for (int r = lane; r < p.M; r += WAVE) {
+        const double d = S.D[r];
+        if (d != 0.0) { // inactive rows keep e = 0
+            int t, lr;
+            row_decode(p, r, t, lr);
+            S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * NZ) - S.e[r];
+        }
+    }
+    __syncthreads();
+    // multipliers of the fixed binaries from the stationarity row of their component
+    const bool own_g = gsrc && gsrc != S.g;
+    for (int o = lane; o < T * NUB; o += WAVE) {
+        const int t = o / NUB, b = o - t * NUB;
+        double a = 0;
+        if (S.fix[o] >= 0) {
+            const int c = NX + NUC + b;
+            a = own_g ? gs * gsrc[t * NZ + c] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NZ; j++) a -= S.P[c * NZ + j] * dw[t * NZ + j];
+            a -= ccol_dot<D>(p, S, t, c, S.e);
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += S.AB[l * NZ + c] * dlam[(t + 1) * NX + l];
+        }
+        dnuf[o] = a;
+    }
+    __syncthreads();
+    FSTAMP(10);
+}
+
+template <class D>
+DEV void kkt_dispatch(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+                      const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
+{
+    if constexpr (D::kNX > 0) kkt_solve_reg<D>(p, S, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
+    else kkt_solve<D>(p, S, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
 }
 
 // f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
@@ -396,7 +778,7 @@ DEV double lin_obj(const DevProb &p, const Lds &S, int lane, const ldsd *lam, co
         if (v != 0.0) {
             int t, lr;
             row_decode(p, r, t, lr);
-            a += hrow(p, S, t, lr) * v;
+            a += hrow(p, S, lr) * v;
         }
     }
     return wave_sum(a);
@@ -412,20 +794,21 @@ template <class D> DEV void set_prescribed(const DevProb &p, const Lds &S, int l
 
 // One interior-point solve of the node with / without the terminal-set rows.
 // Returns status; tau and the iteration count through references.
-template <class D>
-DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int term_on, int &iters, double &tau_out,
+template <class D, int RS>
+DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int term_on, int &iters, double &tau_out,
                   double *trace)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
+    const int nslot = RS > 0 ? RS : p.Mpad / WAVE;
     int mact = 0;
-    for (int r = lane; r < M; r += WAVE) {
+    ROWS_BEGIN(k, r)
         int t, lr;
         row_decode(p, r, t, lr);
         const bool on = row_active<D>(p, S.fix, t, lr, term_on);
         mact += on;
-        R.s[r] = 1.0;
+        R.s(k, r) = 1.0;
         S.z[r] = on ? 1.0 : 0.0;
-    }
+    ROWS_END
     mact = (int)wave_sum((double)mact);
     for (int i = lane; i < n; i += WAVE) S.w[i] = 0.0;
     for (int i = lane; i < (T + 1) * nx; i += WAVE) S.lam[i] = 0.0;
@@ -441,6 +824,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
 #ifdef HMPC_STAMPS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+    long long facc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     for (it = 0; it <= p.max_iter; it++) {
         STAMP(7);
@@ -467,7 +851,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
                 if (j < nx) a += S.lam[t * nx + j];
                 for (int l = 0; l < nx; l++) a -= S.AB[l * nz + j] * S.lam[(t + 1) * nx + l];
                 if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
-                a += ccol_dot(p, S, t, j, S.z + t * p.mreg);
+                a += ccol_dot<D>(p, S, t, j, S.z);
             }
             const double v = S.Pw[o] + a;
             S.rd[o] = v;
@@ -484,20 +868,20 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
             rcinf = fmax(rcinf, fabs(a));
         }
         double hz = 0, sz = 0, zinf = 0;
-        for (int r = lane; r < M; r += WAVE) {
+        ROWS_BEGIN(k, r)
             int t, lr;
             row_decode(p, r, t, lr);
             double a = 0;
             if (row_active<D>(p, S.fix, t, lr, term_on)) {
-                const double zr = S.z[r], sr = R.s[r], hh = hrow(p, S, t, lr);
-                a = sr - hh * tau + crow_dot(p, S, t, lr, S.w + t * nz);
+                const double zr = S.z[r], sr = R.s(k, r), hh = hrow(p, S, lr);
+                a = sr - hh * tau + crow_dot<D>(p, S, lr, S.w + t * nz);
                 hz += hh * zr;
                 sz += sr * zr;
                 zinf = fmax(zinf, zr);
             }
-            R.rc[r] = a;
+            R.rc(k, r) = a;
             rcinf = fmax(rcinf, fabs(a));
-        }
+        ROWS_END
         for (int o = lane; o < (T + 1) * nx; o += WAVE) yinf = fmax(yinf, fabs(S.lam[o]));
         for (int o = lane; o < T * nub; o += WAVE) {
             yinf = fmax(yinf, fabs(S.nuf[o]));
@@ -535,26 +919,31 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
         if (it == p.max_iter) break;
 
         // ---------------- factorisation ----------------
-        for (int r = lane; r < M; r += WAVE) {
+        ROWS_BEGIN(k, r)
             const double zr = S.z[r]; // zero on inactive rows
-            const double d = zr != 0.0 ? zr / R.s[r] : 0.0;
+            const double d = zr != 0.0 ? zr / R.s(k, r) : 0.0;
             int t, lr;
             row_decode(p, r, t, lr);
             S.D[r] = d;
-            S.e[r] = d * hrow(p, S, t, lr); // right-hand side of the constant direction
-        }
+            S.e[r] = d * hrow(p, S, lr); // right-hand side of the constant direction
+        ROWS_END
         __syncthreads();
         STAMP(1);
-        if (factor<D>(p, S, lane) != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
+        int frc;
+        if constexpr (D::kNX > 0) frc = factor_reg<D>(p, S, lane FSTAMP_PASS);
+        else frc = factor<D>(p, S, lane);
+        if (frc != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
         STAMP(2);
 
         // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-        kkt_solve<D>(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1);
+        kkt_dispatch<D>(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
         STAMP(3);
         double g1 = 0;
         for (int o = lane; o < n; o += WAVE) g1 += S.Pw[o] * S.w1[o];
         g1 = wave_sum(g1) * 2.0 / tau;
-        for (int r = lane; r < M; r += WAVE) R.z1[r] = S.e[r];
+        ROWS_BEGIN(k, r)
+            R.z1(k, r) = S.e[r];
+        ROWS_END
         const double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
         const double den = kap / tau + wPw / (tau * tau) - g1 - fyhz1;
 
@@ -563,19 +952,19 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
             const double lin = pass == 0 ? 1.0 : 1.0 - sigma;
             const double dkap_rhs = tau * kap + (pass ? dtau_a * dkap_a - sigma * mu : 0.0);
             __syncthreads();
-            for (int r = lane; r < M; r += WAVE) {
+            ROWS_BEGIN(k, r)
                 double v = 0;
                 const double d = S.D[r];
                 if (d != 0.0) { // active row
                     const double zr = S.z[r];
-                    const double dsr = R.s[r] * zr + (pass ? R.prod[r] - sigma * mu : 0.0);
-                    v = d * (-lin * R.rc[r] + dsr / zr);
+                    const double dsr = R.s(k, r) * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
+                    v = d * (-lin * R.rc(k, r) + dsr / zr);
                 }
                 S.e[r] = v;
-            }
+            ROWS_END
             __syncthreads();
             STAMP(4);
-            kkt_solve<D>(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2);
+            kkt_dispatch<D>(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
             STAMP(3);
             double g2 = 0;
             for (int o = lane; o < n; o += WAVE) g2 += S.Pw[o] * S.w2[o];
@@ -587,11 +976,11 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
             for (int o = lane; o < n; o += WAVE) S.w2[o] += dtau * S.w1[o];
             for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += dtau * S.lam1[o];
             for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += dtau * S.nuf1[o];
-            for (int r = lane; r < M; r += WAVE) {
-                const double v = S.D[r] != 0.0 ? S.e[r] + dtau * R.z1[r] : 0.0;
+            ROWS_BEGIN(k, r)
+                const double v = S.D[r] != 0.0 ? S.e[r] + dtau * R.z1(k, r) : 0.0;
                 S.e[r] = v;
-                R.dz[r] = v;
-            }
+                R.dz(k, r) = v;
+            ROWS_END
             __syncthreads();
             if (pass == 1 && p.refine) {
                 // residual of the three linear blocks at the combined direction (x_0 and fixed
@@ -607,7 +996,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
                     } else {
                         if (j < nx) a -= S.lam2[t * nx + j];
                         for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * S.lam2[(t + 1) * nx + l];
-                        a -= ccol_dot(p, S, t, j, S.e + t * p.mreg);
+                        a -= ccol_dot<D>(p, S, t, j, S.e);
                         if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a = 0.0;
                         if (t == 0 && j < nx) a = 0.0;
                     }
@@ -620,44 +1009,46 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
                     S.edyn[o] = a;
                 }
                 __syncthreads();
-                for (int r = lane; r < M; r += WAVE) {
+                ROWS_BEGIN(k, r)
                     double v = 0;
                     const double d = S.D[r];
                     if (d != 0.0) {
                         int t, lr;
                         row_decode(p, r, t, lr);
-                        const double zr = S.z[r], sr = R.s[r];
-                        const double dsr = sr * zr + R.prod[r] - sigma * mu;
-                        const double a = -lin * R.rc[r] + dsr / zr + dtau * hrow(p, S, t, lr) + S.e[r] * sr / zr -
-                                         crow_dot(p, S, t, lr, S.w2 + t * nz);
+                        const double zr = S.z[r], sr = R.s(k, r);
+                        const double dsr = sr * zr + R.prod(k, r) - sigma * mu;
+                        const double a = -lin * R.rc(k, r) + dsr / zr + dtau * hrow(p, S, lr) + S.e[r] * sr / zr -
+                                         crow_dot<D>(p, S, lr, S.w2 + t * nz);
                         v = d * a;
                     }
                     S.e[r] = v;
-                }
+                ROWS_END
                 __syncthreads();
                 STAMP(5);
-                kkt_solve<D>(p, S, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1);
+                kkt_dispatch<D>(p, S, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
                 STAMP(3);
                 for (int o = lane; o < n; o += WAVE) S.w2[o] += S.w1[o];
                 for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += S.lam1[o];
                 for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += S.nuf1[o];
-                for (int r = lane; r < M; r += WAVE)
-                    if (S.D[r] != 0.0) R.dz[r] += S.e[r];
+                ROWS_BEGIN(k, r)
+                    if (S.D[r] != 0.0) R.dz(k, r) += S.e[r];
+                ROWS_END
             }
             // slack step from the complementarity row ; step to the boundary
             double amax = 1e30;
             if (dtau < 0) amax = fmin(amax, -tau / dtau);
             if (dkap < 0) amax = fmin(amax, -kap / dkap);
-            for (int r = lane; r < M; r += WAVE) {
-                if (S.D[r] == 0.0) continue;
-                const double dz = R.dz[r], sr = R.s[r], zr = S.z[r];
-                const double dsr = sr * zr + (pass ? R.prod[r] - sigma * mu : 0.0);
-                const double ds = -(dsr + sr * dz) / zr;
-                if (dz < 0) amax = fmin(amax, -zr / dz);
-                if (ds < 0) amax = fmin(amax, -sr / ds);
-                if (pass == 0) R.prod[r] = ds * dz;
-                else R.rc[r] = ds; // row residual no longer needed this iteration
-            }
+            ROWS_BEGIN(k, r)
+                if (S.D[r] != 0.0) {
+                    const double dz = R.dz(k, r), sr = R.s(k, r), zr = S.z[r];
+                    const double dsr = sr * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
+                    const double ds = -(dsr + sr * dz) / zr;
+                    if (dz < 0) amax = fmin(amax, -zr / dz);
+                    if (ds < 0) amax = fmin(amax, -sr / ds);
+                    if (pass == 0) R.prod(k, r) = ds * dz;
+                    else R.rc(k, r) = ds; // row residual no longer needed this iteration
+                }
+            ROWS_END
             amax = wave_min(amax);
             if (pass == 0) {
                 const double aa = fmin(1.0, amax);
@@ -670,11 +1061,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
                 for (int o = lane; o < n; o += WAVE) S.w[o] += alpha * S.w2[o];
                 for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam[o] += alpha * S.lam2[o];
                 for (int o = lane; o < T * nub; o += WAVE) S.nuf[o] += alpha * S.nuf2[o];
-                for (int r = lane; r < M; r += WAVE)
+                ROWS_BEGIN(k, r)
                     if (S.D[r] != 0.0) {
-                        S.z[r] += alpha * R.dz[r];
-                        R.s[r] += alpha * R.rc[r];
+                        S.z[r] += alpha * R.dz(k, r);
+                        R.s(k, r) += alpha * R.rc(k, r);
                     }
+                ROWS_END
                 tau += alpha * dtau;
                 kap += alpha * dkap;
                 __syncthreads();
@@ -688,6 +1080,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
 #ifdef HMPC_STAMPS
     if (trace && lane == 0)
         for (int k = 0; k < 8; k++) trace[2 * 64 * 8 + (term_on ? 8 : 0) + k] = (double)tacc[k];
+    if (trace && lane == 0 && term_on == 0)
+        for (int k = 0; k < 16; k++) trace[2 * 64 * 8 + 16 + k] = (double)facc[k];
 #endif
     iters = it;
     tau_out = tau;
@@ -698,8 +1092,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, const Rows &R, int lane, int t
 template <class D> DEV double terminal_violation(const DevProb &p, const Lds &S, int lane, double tau)
 {
     double tv = -1e300;
-    for (int lr = p.nc + lane; lr < p.ncL; lr += WAVE) {
-        const double a = row_dot(S.L1, lr, S.w + (p.T - 1) * D::nz(p)) - S.L1.h[lr] * tau;
+    for (int k = lane; k < p.nT; k += WAVE) {
+        const double a = crow_dot<D>(p, S, p.mreg + k, S.w + (p.T - 1) * D::nz(p)) - p.ht[k] * tau;
         tv = fmax(tv, a / tau);
     }
     return wave_max(tv);
@@ -735,21 +1129,19 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     for (int r = lane; r < M; r += WAVE) {
         int t, lr;
         row_decode(p, r, t, lr);
-        const int mg = t < T - 1 ? p.nc : p.ncL;
-        if (lr < mg) {
-            const double sc = p.st[t < T - 1 ? 0 : 1].scale[lr];
+        if (lr < p.nc || lr >= p.mreg) { // [F G] rows and terminal-set rows are the reference's mu_t
+            const double sc = lr < p.nc ? p.reg.scale[lr] : p.sct[lr - p.mreg];
             const double v = S.z[r] * scale * sc;
-            if (dual) dual[o_mu + t * p.nc + lr] = v;
-            farkas -= (hrow(p, S, t, lr) / sc) * v;
+            if (dual) dual[o_mu + t * p.nc + (lr < p.nc ? lr : p.nc + (lr - p.mreg))] = v;
+            farkas -= (hrow(p, S, lr) / sc) * v;
         }
     }
     for (int o = lane; o < T * nub; o += WAVE) {
         const int t = o / nub, b = o - t * nub;
-        const int mg = t < T - 1 ? p.nc : p.ncL;
         double lo, hi;
         if (S.fix[o] < 0) {
-            lo = S.z[t * p.mreg + mg + b] * scale;
-            hi = S.z[t * p.mreg + mg + nub + b] * scale;
+            lo = S.z[t * p.mreg + p.nc + b] * scale;
+            hi = S.z[t * p.mreg + p.nc + nub + b] * scale;
             farkas -= hi;
         } else {
             const double v = S.nuf[o] * scale;
@@ -797,7 +1189,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     }
 }
 
-template <int NX_, int NU_, int NUB_>
+template <int NX_, int NU_, int NUB_, int RS>
 __global__ void __launch_bounds__(WAVE)
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
@@ -814,7 +1206,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
         S.z = take(M); S.D = take(M); S.e = take(M);
         S.Minv = take(T * nu * nu); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nx * nx);
-        S.mb = take(T * nz); S.mus = take(T * nu);
+        S.mb = take(T * nz); S.mus = take(T * nu); S.ru = take(T * nu);
         S.rd = take(n); S.rdyn = take(T * nx); S.Pw = take(n); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         S.w2 = take(n); S.lam2 = take((T + 1) * nx); S.nuf2 = take(T * nub);
@@ -830,7 +1222,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsi *rptr0 = takei(p.mreg + 1), *rcol0 = takei(p.nnz0), *cptr0 = takei(nz + 1), *crow0 = takei(p.nnz0);
         ldsi *gptr0 = takei(ne + 1), *grow0 = takei(p.nng0);
         // stage the node-independent data
-        const SparseStage &g0 = p.st[0], &g1 = p.st[1];
+        const SparseStage &g0 = p.reg;
         for (int i = lane; i < nx * nz; i += WAVE) {
             const int l = i / nz, j = i - l * nz;
             S.AB[i] = j < nx ? p.A[l * nx + j] : p.B[l * nu + (j - nx)];
@@ -845,13 +1237,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int i = lane; i < ne + 1; i += WAVE) gptr0[i] = g0.gptr[i];
         for (int i = lane; i < ne; i += WAVE) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
-        S.L1 = ListsG{g1.rptr, g1.rcol, g1.cptr, g1.crow, g1.gptr, g1.grow, g1.rval, g1.cval, g1.gval, g1.h};
+        S.term_on = 0;
     }
-    Rows R;
-    {
-        double *base = rows_ws + (size_t)blockIdx.x * 5 * p.Mpad;
-        R.s = base; R.rc = base + p.Mpad; R.z1 = base + 2 * p.Mpad; R.dz = base + 3 * p.Mpad; R.prod = base + 4 * p.Mpad;
-    }
+    Rows<RS> R;
+    R.bind(rows_ws + (size_t)blockIdx.x * 5 * p.Mpad, p.Mpad);
     for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
         __syncthreads();
         for (int o = lane; o < T * nub; o += WAVE) S.fix[o] = fixg[(size_t)qp * T * nub + o];
@@ -863,10 +1252,11 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
         // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
         // is the node's optimum.  Otherwise solve again with every row.
-        const int first = (p.ncL > p.nc && p.lazy) ? 0 : 1;
+        const int first = (p.nT > 0 && p.lazy) ? 0 : 1;
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
-            status = ipm_solve<D>(p, S, R, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
+            S.term_on = term_on;
+            status = ipm_solve<D, RS>(p, S, R, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -881,12 +1271,21 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
 }
 
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
-// nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries) and the
-// generic run-time-sized kernel for everything else.
+// nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries) with the
+// row slots that cover their horizons, and the generic run-time-sized kernel for everything else.
 typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *);
 static hmpc_kernel_t hmpc_pick_kernel(const DevProb &p)
 {
-    if (p.nx == 4 && p.nu == 7 && p.nub == 4) return hmpc_qp_kernel<4, 7, 4>;
-    if (p.nx == 4 && p.nu == 4 && p.nub == 2) return hmpc_qp_kernel<4, 4, 2>;
-    return hmpc_qp_kernel<0, 0, 0>;
+    const int slots = p.Mpad / WAVE;
+    if (getenv("HMPC_FORCE_GENERIC")) return hmpc_qp_kernel<0, 0, 0, 0>;
+    if (p.nx == 4 && p.nu == 7 && p.nub == 4) {
+        if (slots <= 8) return hmpc_qp_kernel<4, 7, 4, 8>;    // N = 10 (462 rows)
+        if (slots <= 13) return hmpc_qp_kernel<4, 7, 4, 13>;  // N = 20 (822 rows)
+        return hmpc_qp_kernel<4, 7, 4, 0>;
+    }
+    if (p.nx == 4 && p.nu == 4 && p.nub == 2) {
+        if (slots <= 15) return hmpc_qp_kernel<4, 4, 2, 15>;  // T = 40 (928 rows)
+        return hmpc_qp_kernel<4, 4, 2, 0>;
+    }
+    return hmpc_qp_kernel<0, 0, 0, 0>;
 }
