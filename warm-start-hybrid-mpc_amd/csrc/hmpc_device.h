@@ -44,13 +44,14 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
     size_t d = 0, i = 0;
-    d += n + (T + 1) * nx + T * nub;                                      // w lam nuf
+    const size_t nus = nu * (nu + 1) / 2, nxs = nx * (nx + 1) / 2;
+    const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nz * nu + nx * nz;
+    d += dir;                                                             // w lam nuf
     d += 3 * M;                                                           // z D e
-    d += T * nu * nu + T * nu * nx + (T + 1) * nx * nx + T * nz + 2 * T * nu; // Minv Kg Pr mb mus ru
-    d += n + T * nx + n + n + (T + 1) * nx;                               // rd rdyn Pw g pv
-    d += 2 * (n + (T + 1) * nx + T * nub);                                // w1.. w2..
-    d += T * nx;                                                          // edyn
-    d += nz * nz + nz * nu + nx * nz + nx + nz;                           // Mm E PA q mv
+    d += T * nus + T * nu * nx + (T + 1) * nxs + T * nu;                  // Minv Kg Pr mus
+    d += n + T * nx + n + (T + 1) * nx;                                   // rd rdyn g pv
+    d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
+    d += nx + nz;                                                         // q mv
     d += nx;                                                              // x0
     d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
     d += p.mreg + 2 * (size_t)p.nnz0 + p.nng0;                            // h0 rval0 cval0 gval0

@@ -93,10 +93,9 @@ typedef Lists<const ldsi *, const ldsd *> ListsL;
 
 struct Lds {
     ldsd *w, *lam, *nuf, *z, *D, *e;
-    ldsd *Minv, *Kg, *Pr, *mb, *mus, *ru;
-    ldsd *rd, *rdyn, *Pw, *g, *pv;
+    ldsd *Minv, *Kg, *Pr, *mus;   // Minv and Pr: packed lower triangles per stage
+    ldsd *rd, *rdyn, *g, *pv;
     ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
-    ldsd *edyn;
     ldsd *Mm, *E, *PA, *q, *mv;
     ldsd *x0;
     ldsi *fix;
@@ -173,6 +172,9 @@ template <class D> DEV bool row_active(const DevProb &p, const ldsi *fix, int t,
     if (b >= nub) b -= nub;
     return fix[t * nub + b] < 0;
 }
+
+// index of (i, l) in a symmetric matrix stored as its packed lower triangle
+DEV int sym(int i, int l) { return i >= l ? i * (i + 1) / 2 + l : l * (l + 1) / 2 + i; }
 
 // Sparse dot products.  Each term is two dependent loads (index, then the indexed value); the
 // terms are independent, so the loops are unrolled four wide to keep four chains in flight.
@@ -272,11 +274,15 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
-    for (int i = lane; i < nx * nx; i += WAVE) S.Pr[T * nx * nx + i] = S.PT[i];
+    const int nxs = nx * (nx + 1) / 2, nus = nu * (nu + 1) / 2;
+    for (int e = lane; e < nx * nx; e += WAVE) {
+        const int i = e / nx, j = e - i * nx;
+        if (i >= j) S.Pr[T * nxs + sym(i, j)] = S.PT[e];
+    }
     __syncthreads();
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Pn = S.Pr + (t + 1) * nx * nx;
+        const ldsd *Pn = S.Pr + (t + 1) * nxs;
         const ldsi *fx = S.fix + t * nub;
         int nfixed = 0;
         for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
@@ -290,7 +296,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         for (int e = lane; e < nx * nz; e += WAVE) {
             const int i = e / nz, j = e - i * nz;
             double a = 0;
-            for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * S.AB[l * nz + j];
+            for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * S.AB[l * nz + j];
             S.PA[e] = a;
         }
         for (int e = lane; e < nz * nu; e += WAVE) {
@@ -313,7 +319,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
                 double a = 0;
                 for (int b = 0; b < nub; b++)
                     if (fx[b] == 1) a += S.Mm[i * nz + nx + nuc + b];
-                S.mb[t * nz + i] = a;
+                S.g[t * nz + i] = a;
             }
             __syncthreads();
             for (int e = lane; e < nz * nz; e += WAVE) {
@@ -324,7 +330,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             }
             __syncthreads();
         } else {
-            for (int i = lane; i < nz; i += WAVE) S.mb[t * nz + i] = 0.0;
+            for (int i = lane; i < nz; i += WAVE) S.g[t * nz + i] = 0.0;
         }
         // elimination of the free inputs, pivot order u_0 .. u_{nu-1}
         for (int j = 0; j < nu; j++) {
@@ -363,7 +369,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         // E[u][:] = unit-lower inverse factor, pivots on the diagonal of Mm[u][u].
         for (int e = lane; e < nx * nx; e += WAVE) {
             const int i = e / nx, j = e - i * nx;
-            S.Pr[t * nx * nx + e] = S.Mm[i * nz + j];
+            if (i >= j) S.Pr[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
         }
         for (int e = lane; e < nu * nx; e += WAVE) {
             const int i = e / nx, c = e - i * nx;
@@ -371,10 +377,10 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         }
         for (int e = lane; e < nu * nu; e += WAVE) {
             const int i = e / nu, j = e - i * nu;
+            if (i < j) continue;
             double a = 0;
-            for (int l = (i > j ? i : j); l < nu; l++)
-                a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] * S.mv[l];
-            S.Minv[t * nu * nu + e] = a;
+            for (int l = i; l < nu; l++) a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] * S.mv[l];
+            S.Minv[t * nus + sym(i, j)] = a;
         }
         __syncthreads();
     }
@@ -393,11 +399,15 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
     FSTAMP_DECL;
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
     const int T = p.T;
-    for (int i = lane; i < NX * NX; i += WAVE) S.Pr[T * NX * NX + i] = S.PT[i];
+    constexpr int NXS = NX * (NX + 1) / 2, NUS = NU * (NU + 1) / 2;
+    for (int e = lane; e < NX * NX; e += WAVE) {
+        const int i = e / NX, j = e - i * NX;
+        if (i >= j) S.Pr[T * NXS + sym(i, j)] = S.PT[e];
+    }
     __syncthreads();
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Pn = S.Pr + (t + 1) * NX * NX;
+        const ldsd *Pn = S.Pr + (t + 1) * NXS;
         const ldsi *fx = S.fix + t * NUB;
         // phase 1 (LDS): M = P + C' D C by Gram lists ; PA = Pn [A B]
         for (int e = lane; e < NE; e += WAVE) {
@@ -410,7 +420,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             const int i = e / NZ, j = e - i * NZ;
             double a = 0;
 #pragma unroll
-            for (int l = 0; l < NX; l++) a += Pn[i * NX + l] * S.AB[l * NZ + j];
+            for (int l = 0; l < NX; l++) a += Pn[sym(i, l)] * S.AB[l * NZ + j];
             S.PA[e] = a;
         }
         __syncthreads();
@@ -446,7 +456,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 }
             if (lane == 0) {
 #pragma unroll
-                for (int i = 0; i < NZ; i++) S.mb[t * NZ + i] = mbv[i];
+                for (int i = 0; i < NZ; i++) S.g[t * NZ + i] = mbv[i];
             }
 #pragma unroll
             for (int b = 0; b < NUB; b++)
@@ -460,7 +470,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                     }
                 }
         } else if (lane < NZ) {
-            S.mb[t * NZ + lane] = 0.0;
+            S.g[t * NZ + lane] = 0.0;
         }
         FSTAMP(2);
         double dinv[NU];
@@ -490,7 +500,8 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         // write back: Schur complement (state lanes), gain and unit-lower inverse factor (E lanes)
         if (lane < NX) {
 #pragma unroll
-            for (int i = 0; i < NX; i++) S.Pr[t * NX * NX + i * NX + lane] = col[i];
+            for (int i = 0; i < NX; i++)
+                if (i >= lane) S.Pr[t * NXS + sym(i, lane)] = col[i];
         } else if (lane >= NZ && lane < NZ + NU) {
             const int c = lane - NZ;
 #pragma unroll
@@ -503,12 +514,13 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         // phase 3: M_uu^{-1} = E_u' diag(1/pivot) E_u ; overlaps with the next stage's phase 1
         for (int e = lane; e < NU * NU; e += WAVE) {
             const int i = e / NU, j = e - i * NU;
-            const int lo = i > j ? i : j;
-            double a = 0;
+            if (i >= j) {
+                double a = 0;
 #pragma unroll
-            for (int l = 0; l < NU; l++)
-                if (l >= lo) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * dinv[l];
-            S.Minv[t * NU * NU + e] = a;
+                for (int l = 0; l < NU; l++)
+                    if (l >= i) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * dinv[l];
+                S.Minv[t * NUS + sym(i, j)] = a;
+            }
         }
         FSTAMP(5);
     }
@@ -530,34 +542,30 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     // g = rhs_d + C' e  (column lists)
+    // S.g <- (the factorisation's mb, left in S.g, if useb) - (rhs_d + C' e)
     for (int o = lane; o < T * nz; o += WAVE) {
         const int t = o / nz, j = o - t * nz;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
-        S.g[o] = a;
+        S.g[o] = (useb ? S.g[o] : 0.0) - a;
     }
-    for (int j = lane; j < nx; j += WAVE) {
-        const double a = gsrc ? gs * gsrc[T * nz + j] : 0.0;
-        S.g[T * nz + j] = a;
-        S.pv[T * nx + j] = -a;
-    }
+    for (int j = lane; j < nx; j += WAVE) S.pv[T * nx + j] = -(gsrc ? gs * gsrc[T * nz + j] : 0.0);
     __syncthreads();
     // backward sweep
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *qv = S.pv + (t + 1) * nx;
         if (csrc) {
-            const ldsd *Pn = S.Pr + (t + 1) * nx * nx;
+            const ldsd *Pn = S.Pr + (t + 1) * (nx * (nx + 1) / 2);
             for (int i = lane; i < nx; i += WAVE) {
                 double a = S.pv[(t + 1) * nx + i];
-                for (int l = 0; l < nx; l++) a += Pn[i * nx + l] * cs * csrc[t * nx + l];
+                for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * cs * csrc[t * nx + l];
                 S.q[i] = a;
             }
             __syncthreads();
             qv = S.q;
         }
         for (int j = lane; j < nz; j += WAVE) {
-            double a = -S.g[t * nz + j];
+            double a = S.g[t * nz + j];
             for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * qv[l];
-            if (useb) a += S.mb[t * nz + j];
             if (j >= nx + nuc) {
                 const int f = S.fix[t * nub + (j - nx - nuc)];
                 if (f >= 0) a = (useb && f == 1) ? -1.0 : 0.0;
@@ -581,7 +589,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
         for (int i = lane; i < nu; i += WAVE) {
             double a = 0;
             for (int l = 0; l < nx; l++) a += S.Kg[t * nu * nx + i * nx + l] * x[l];
-            for (int l = 0; l < nu; l++) a += S.Minv[t * nu * nu + i * nu + l] * S.mus[t * nu + l];
+            for (int l = 0; l < nu; l++) a += S.Minv[t * (nu * (nu + 1) / 2) + sym(i, l)] * S.mus[t * nu + l];
             dw[t * nz + nx + i] = -a;
         }
         __syncthreads();
@@ -596,7 +604,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     for (int o = lane; o < (T + 1) * nx; o += WAVE) {
         const int t = o / nx, i = o - t * nx;
         double a = S.pv[o];
-        for (int l = 0; l < nx; l++) a += S.Pr[t * nx * nx + i * nx + l] * dw[t * nz + l];
+        for (int l = 0; l < nx; l++) a += S.Pr[t * (nx * (nx + 1) / 2) + sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
     for (int r = lane; r < p.M; r += WAVE) {
@@ -643,7 +651,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     for (int o = lane; o < T * NZ; o += WAVE) {
         const int t = o / NZ, j = o - t * NZ;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
-        S.g[o] = (useb ? S.mb[o] : 0.0) - a;
+        S.g[o] = (useb ? S.g[o] : 0.0) - a;
     }
     double pvr = 0.0; // lane i < NX: p_{t+1}[i]
     if (lane < NX) {
@@ -666,7 +674,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
             double qv = pvr;
             if (csrc && lane < NX) {
 #pragma unroll
-                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * NX * NX + lane * NX + l] * cs * csrc[t * NX + l];
+                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * (NX * (NX + 1) / 2) + sym(lane, l)] * cs * csrc[t * NX + l];
             }
             double m = mpre;
 #pragma unroll
@@ -687,8 +695,8 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
         const int t = o / NU, i = o - t * NU;
         double a = 0;
 #pragma unroll
-        for (int l = 0; l < NU; l++) a += S.Minv[t * NU * NU + i * NU + l] * S.mus[t * NU + l];
-        S.ru[o] = a;
+        for (int l = 0; l < NU; l++) a += S.Minv[t * (NU * (NU + 1) / 2) + sym(i, l)] * S.mus[t * NU + l];
+        S.g[o] = a; // the stage gradients are consumed: their storage takes M_uu^{-1} m_u
     }
     __syncthreads();
     FSTAMP(8);
@@ -701,7 +709,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
             double kgr[NX];
 #pragma unroll
             for (int l = 0; l < NX; l++) kgr[l] = lane < NU ? S.Kg[t * NU * NX + lane * NX + l] : 0.0;
-            const double ru = lane < NU ? S.ru[t * NU + lane] : 0.0;
+            const double ru = lane < NU ? S.g[t * NU + lane] : 0.0;
             const double cdy = (csrc && lane < NX) ? cs * csrc[t * NX + lane] : 0.0;
             double u = -ru, xn = cdy;
 #pragma unroll
@@ -725,7 +733,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
         const int t = o / NX, i = o - t * NX;
         double a = S.pv[o];
 #pragma unroll
-        for (int l = 0; l < NX; l++) a += S.Pr[t * NX * NX + i * NX + l] * dw[t * NZ + l];
+        for (int l = 0; l < NX; l++) a += S.Pr[t * (NX * (NX + 1) / 2) + sym(i, l)] * dw[t * NZ + l];
         dlam[o] = -a;
     }
     for (int r = lane; r < p.M; r += WAVE) {
@@ -792,6 +800,22 @@ template <class D> DEV void set_prescribed(const DevProb &p, const Lds &S, int l
         if (S.fix[o] >= 0) S.w[(o / nub) * D::nz(p) + D::nx(p) + D::nuc(p) + (o % nub)] = S.fix[o] * tau;
 }
 
+// w' P v (per-lane partial sum) for a direction v
+template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, const ldsd *v)
+{
+    const int nx = D::nx(p), nz = D::nz(p), T = p.T, n = T * nz + nx;
+    double acc = 0;
+    for (int o = lane; o < n; o += WAVE) {
+        const int t = o / nz < T ? o / nz : T;
+        const int i = o - t * nz, dim = t < T ? nz : nx;
+        const ldsd *PP = t < T ? S.P : S.PT;
+        double a = 0;
+        for (int j = 0; j < dim; j++) a += PP[i * dim + j] * v[t * nz + j];
+        acc += a * S.w[o];
+    }
+    return acc;
+}
+
 // One interior-point solve of the node with / without the terminal-set rows.
 // Returns status; tau and the iteration count through references.
 template <class D, int RS>
@@ -836,7 +860,6 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             const ldsd *PP = t < T ? S.P : S.PT;
             double a = 0;
             for (int j = 0; j < dim; j++) a += PP[i * dim + j] * S.w[t * nz + j];
-            S.Pw[o] = a;
             wPw += a * S.w[o];
         }
         wPw = wave_sum(wPw);
@@ -853,7 +876,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
                 a += ccol_dot<D>(p, S, t, j, S.z);
             }
-            const double v = S.Pw[o] + a;
+            double pw = 0; // (P w)_o
+            {
+                const int dim = t < T ? nz : nx;
+                const ldsd *PP = t < T ? S.P : S.PT;
+                for (int l = 0; l < dim; l++) pw += PP[j * dim + l] * S.w[t * nz + l];
+            }
+            const double v = pw + a;
             S.rd[o] = v;
             rdinf = fmax(rdinf, fabs(v));
             certinf = fmax(certinf, fabs(a));
@@ -939,7 +968,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         kkt_dispatch<D>(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
         STAMP(3);
         double g1 = 0;
-        for (int o = lane; o < n; o += WAVE) g1 += S.Pw[o] * S.w1[o];
+        g1 = wPv<D>(p, S, lane, S.w1);
         g1 = wave_sum(g1) * 2.0 / tau;
         ROWS_BEGIN(k, r)
             R.z1(k, r) = S.e[r];
@@ -967,7 +996,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             kkt_dispatch<D>(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
             STAMP(3);
             double g2 = 0;
-            for (int o = lane; o < n; o += WAVE) g2 += S.Pw[o] * S.w2[o];
+            g2 = wPv<D>(p, S, lane, S.w2);
             g2 = wave_sum(g2) * 2.0 / tau;
             const double fyhz2 = lin_obj<D>(p, S, lane, S.lam2, S.nuf2, S.e);
             const double dtau = (lin * rg - dkap_rhs / tau + g2 + fyhz2) / den;
@@ -1006,7 +1035,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     const int t = o / nx, i = o - t * nx;
                     double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
                     for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * S.w2[t * nz + l];
-                    S.edyn[o] = a;
+                    S.rdyn[o] = a; // in place: the dynamics residual is recomputed next iteration
                 }
                 __syncthreads();
                 ROWS_BEGIN(k, r)
@@ -1025,7 +1054,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 ROWS_END
                 __syncthreads();
                 STAMP(5);
-                kkt_dispatch<D>(p, S, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+                kkt_dispatch<D>(p, S, lane, S.g, 1.0, false, S.rdyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
                 STAMP(3);
                 for (int o = lane; o < n; o += WAVE) S.w2[o] += S.w1[o];
                 for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += S.lam1[o];
@@ -1205,13 +1234,17 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         auto take = [&](int cnt) { ldsd *r = q; q += cnt; return r; };
         S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
         S.z = take(M); S.D = take(M); S.e = take(M);
-        S.Minv = take(T * nu * nu); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nx * nx);
-        S.mb = take(T * nz); S.mus = take(T * nu); S.ru = take(T * nu);
-        S.rd = take(n); S.rdyn = take(T * nx); S.Pw = take(n); S.g = take(n); S.pv = take((T + 1) * nx);
+        const int nus = nu * (nu + 1) / 2, nxs = nx * (nx + 1) / 2;
+        S.Minv = take(T * nus); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nxs);
+        S.mus = take(T * nu);
+        S.rd = take(n); S.rdyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
-        S.w2 = take(n); S.lam2 = take((T + 1) * nx); S.nuf2 = take(T * nub);
-        S.edyn = take(T * nx);
-        S.Mm = take(nz * nz); S.E = take(nz * nu); S.PA = take(nx * nz); S.q = take(nx); S.mv = take(nz);
+        // the second direction is dead while a factorisation runs: its storage doubles as the
+        // factorisation scratch (stage matrix, carried identity block, Pn [A B])
+        const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + nz * nu + nx * nz;
+        S.w2 = take(dir2 > fscr ? dir2 : fscr); S.lam2 = S.w2 + n; S.nuf2 = S.lam2 + (T + 1) * nx;
+        S.Mm = S.w2; S.E = S.Mm + nz * nz; S.PA = S.E + nz * nu;
+        S.q = take(nx); S.mv = take(nz);
         S.x0 = take(nx);
         S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
         ldsd *h0 = take(p.mreg), *rval0 = take(p.nnz0), *cval0 = take(p.nnz0), *gval0 = take(p.nng0);
