@@ -50,6 +50,8 @@
 #define ST_INFEASIBLE 1
 #define ST_MAXITER 2
 #define ST_NUMERICAL 3
+/* iterative refinement pays only near the end, where D = z/s spans many orders of magnitude */
+#define REFINE_MU 1e-3
 
 typedef struct {
     int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, nq, nr, nqT;
@@ -545,7 +547,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             for (int i = 0; i < (T + 1) * nx; i++) k->lam2[i] += dtau * k->lam1[i];
             for (int i = 0; i < T * nub; i++) k->nuf2[i] += dtau * k->nuf1[i];
             for (int r = 0; r < M; r++) k->z2[r] = k->act[r] ? k->z2[r] + dtau * k->z1[r] : 0.0;
-            if (pass == 1 && refine) {
+            if (pass == 1 && refine && mu < REFINE_MU) {
                 /* one step of iterative refinement against the three linear blocks of the
                  * Newton system at this dtau:  K d = rhs2 + dtau rhs1                      */
                 kkt_residual(p, k, fix, sd, sc, k->rhs_c, dtau, k->w2, k->lam2, k->nuf2, k->z2, k->ed, k->edyn, k->ec);

@@ -1011,7 +1011,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 R.dz(k, r) = v;
             ROWS_END
             __syncthreads();
-            if (pass == 1 && p.refine) {
+            if (pass == 1 && p.refine && mu < 1e-3) { // pays only once D = z/s spans many orders of magnitude
                 // residual of the three linear blocks at the combined direction (x_0 and fixed
                 // binaries are met by construction), then one correction solve
                 for (int o = lane; o < n; o += WAVE) {
