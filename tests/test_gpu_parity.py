@@ -111,9 +111,17 @@ def test_result_is_independent_of_batch_position_and_size():
     perm = np.random.default_rng(0).permutation(700)
     b = ctrl.qp.solve_batch(X0, fix[perm])
     for k in ('obj', 'dual_obj', 'status', 'iters', 'dual'):
-        assert np.array_equal(a[k][perm], b[k], equal_nan=True), k
-    c = ctrl.qp.solve_batch(X0, fix[:1])
-    assert c['obj'][0] == a['obj'][0] and np.array_equal(c['dual'][0], a['dual'][0])
+        assert np.array_equal(a[k][perm], b[k], equal_nan=True), k         # bitwise: position in the batch
+    # bitwise also across batch sizes that use the same launch configuration (all branch-and-bound
+    # rounds are in this class: the exact warm == cold objective of test_controller.py:165-170 relies on it)
+    c, d = ctrl.qp.solve_batch(X0, fix[:1]), ctrl.qp.solve_batch(X0, fix[:40])
+    assert c['obj'][0] == d['obj'][0] and np.array_equal(c['dual'][0], d['dual'][0], equal_nan=True)
+    assert np.array_equal(d['primal'][:40], ctrl.qp.solve_batch(X0, fix[:200])['primal'][:40], equal_nan=True)
+    # across launch configurations (waves per node follow the batch size) the reduction trees differ:
+    # same statuses, values equal to solver accuracy
+    assert np.array_equal(a['status'][:40], d['status'])
+    fin = d['status'] == 0
+    np.testing.assert_allclose(a['obj'][:40][fin], d['obj'][fin], rtol=2e-6, atol=1e-9)
 
 
 def test_edge_cases():

@@ -161,7 +161,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     const int nx = q->nx, nu = q->nu, nz = q->nx + q->nu;
     p.nx = q->nx; p.nu = q->nu; p.nub = q->nub; p.nuc = q->nu - q->nub; p.nz = q->nx + q->nu; p.T = q->T;
     p.nc = q->nc; p.ncL = q->ncT; p.nT = q->ncT - q->nc; p.mreg = q->nc + 2 * q->nub;
-    p.Toff = q->T * p.mreg; p.M = p.Toff + p.nT; p.Mpad = (p.M + 63) / 64 * 64;
+    p.Toff = q->T * p.mreg; p.M = p.Toff + p.nT; p.Mpad = (p.M + 255) / 256 * 256;
     p.n = q->T * p.nz + q->nx; p.ne = p.nz * (p.nz + 1) / 2;
     p.nq = q->nq; p.nr = q->nr; p.nqT = q->nqT;
     p.n_primal = (q->T + 1) * q->nx + q->T * q->nu;
@@ -257,10 +257,11 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         hmpc_destroy(h);
         return fail(HMPC_ETOOBIG, msg);
     }
-    if (hipFuncSetAttribute((const void *)hmpc_pick_kernel(p), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
-        hmpc_destroy(h);
-        return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
-    }
+    for (int nw = 1; nw <= 4; nw *= 2)
+        if (hipFuncSetAttribute((const void *)hmpc_pick_kernel(p, nw).fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+            hmpc_destroy(h);
+            return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
+        }
     int per_cu = (int)(lds_cu / h->lds);
     if (per_cu > 8) per_cu = 8;
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
@@ -318,7 +319,8 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
     const int grid = B < h->max_grid ? B : h->max_grid;
     h->last_grid = grid;
-    hipLaunchKernelGGL(hmpc_pick_kernel(h->dp), dim3(grid), dim3(64), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
+    const hmpc_kernel_choice k = hmpc_pick_kernel(h->dp, hmpc_waves_for(B, h->max_grid));
+    hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace);
     HIPCHK(hipGetLastError());
     return HMPC_OK;

@@ -51,11 +51,11 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
     d += T * nus + T * nu * nx + (T + 1) * nxs + T * nu;                  // Minv Kg Pr mus
     d += n + T * nx + n + (T + 1) * nx;                                   // rd rdyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
-    d += nx + nz;                                                         // q mv
+    d += nx + nz + 40;                                                    // q mv red
     d += nx;                                                              // x0
     d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
     d += p.mreg + 2 * (size_t)p.nnz0 + p.nng0;                            // h0 rval0 cval0 gval0
-    i += T * nub + 2 * (size_t)p.ne;                                      // fix ei ej
+    i += 2 + T * nub + 2 * (size_t)p.ne;                                  // flag fix ei ej
     i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0 + (p.ne + 1) + p.nng0; // rptr0 rcol0 cptr0 crow0 gptr0 grow0
     return d * sizeof(double) + i * sizeof(int);
 }

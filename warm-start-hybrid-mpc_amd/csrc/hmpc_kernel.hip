@@ -69,6 +69,54 @@ DEV double wave_min(double v)
     return v;
 }
 
+// Reduction of N values over the whole workgroup (the node's NW waves): shuffles inside each
+// wave, then one LDS exchange.  ops[i]: 0 sum, 1 max, 2 min.  Deterministic (fixed tree).
+template <class D, int N>
+DEV void block_reduce(double (&v)[N], const int (&op)[N], __attribute__((address_space(3))) double *red, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = op[i] == 0 ? wave_sum(v[i]) : op[i] == 1 ? wave_max(v[i]) : wave_min(v[i]);
+    if constexpr (D::kNW > 1) {
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < N; i++) red[(tid >> 6) * N + i] = v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            double a = red[i];
+#pragma unroll
+            for (int w = 1; w < D::kNW; w++) {
+                const double b = red[w * N + i];
+                a = op[i] == 0 ? a + b : op[i] == 1 ? fmax(a, b) : fmin(a, b);
+            }
+            v[i] = a;
+        }
+        __syncthreads();
+    }
+}
+template <class D> DEV double block_sum(double x, __attribute__((address_space(3))) double *red, int tid)
+{
+    double v[1] = {x};
+    const int op[1] = {0};
+    block_reduce<D, 1>(v, op, red, tid);
+    return v[0];
+}
+template <class D> DEV double block_max(double x, __attribute__((address_space(3))) double *red, int tid)
+{
+    double v[1] = {x};
+    const int op[1] = {1};
+    block_reduce<D, 1>(v, op, red, tid);
+    return v[0];
+}
+template <class D> DEV double block_min(double x, __attribute__((address_space(3))) double *red, int tid)
+{
+    double v[1] = {x};
+    const int op[1] = {2};
+    block_reduce<D, 1>(v, op, red, tid);
+    return v[0];
+}
+
 // Broadcast of one lane's double to the whole wave through two v_readlane (the result is wave
 // uniform and lives in SGPRs: no LDS round trip).  src must be wave uniform.
 DEV double bcast(double v, int src)
@@ -97,6 +145,8 @@ struct Lds {
     ldsd *rd, *rdyn, *g, *pv;
     ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
     ldsd *Mm, *E, *PA, *q, *mv;
+    ldsd *red;         // exchange buffer of the workgroup reductions
+    ldsi *flag;        // wave 0 -> workgroup: factorisation failed
     ldsd *x0;
     ldsi *fix;
     ldsd *AB, *P, *PT; // [A B] (nx x nz), scaled cost Hessians
@@ -107,9 +157,10 @@ struct Lds {
 
 // Problem dimensions: compile-time for the instantiated shapes (index arithmetic folds to
 // immediates, inner loops unroll, divisions become multiplies), run-time for the generic kernel.
-template <int NX_, int NU_, int NUB_>
+template <int NX_, int NU_, int NUB_, int NW_>
 struct Dims {
     static constexpr int kNX = NX_, kNU = NU_, kNUB = NUB_;
+    static constexpr int kNW = NW_, kNT = NW_ * 64; // waves / threads per node (workgroup)
     static DEV int nx(const DevProb &p) { return NX_ > 0 ? NX_ : p.nx; }
     static DEV int nu(const DevProb &p) { return NU_ > 0 ? NU_ : p.nu; }
     static DEV int nub(const DevProb &p) { return NU_ > 0 ? NUB_ : p.nub; }
@@ -146,7 +197,7 @@ struct Rows<0> {
 // loop over the rows of this lane: slot k, row r
 #define ROWS_BEGIN(k, r)                                   \
     _Pragma("unroll") for (int k = 0; k < nslot; k++) {   \
-        const int r = k * WAVE + lane;                     \
+        const int r = k * D::kNT + lane;                   \
         if (r < M) {
 #define ROWS_END }}
 
@@ -275,7 +326,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
     const int nxs = nx * (nx + 1) / 2, nus = nu * (nu + 1) / 2;
-    for (int e = lane; e < nx * nx; e += WAVE) {
+    for (int e = lane; e < nx * nx; e += D::kNT) {
         const int i = e / nx, j = e - i * nx;
         if (i >= j) S.Pr[T * nxs + sym(i, j)] = S.PT[e];
     }
@@ -287,24 +338,24 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         int nfixed = 0;
         for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
         // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B] ; E = identity block on the inputs
-        for (int e = lane; e < ne; e += WAVE) {
+        for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             const double a = S.P[i * nz + j] + gram_entry<D>(p, S, t, e, i, j);
             S.Mm[i * nz + j] = a;
             S.Mm[j * nz + i] = a;
         }
-        for (int e = lane; e < nx * nz; e += WAVE) {
+        for (int e = lane; e < nx * nz; e += D::kNT) {
             const int i = e / nz, j = e - i * nz;
             double a = 0;
             for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * S.AB[l * nz + j];
             S.PA[e] = a;
         }
-        for (int e = lane; e < nz * nu; e += WAVE) {
+        for (int e = lane; e < nz * nu; e += D::kNT) {
             const int i = e / nu, c = e - i * nu;
             S.E[e] = (i == nx + c) ? 1.0 : 0.0;
         }
         __syncthreads();
-        for (int e = lane; e < ne; e += WAVE) {
+        for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             double a = S.Mm[i * nz + j];
             for (int l = 0; l < nx; l++) a += S.AB[l * nz + i] * S.PA[l * nz + j];
@@ -315,14 +366,14 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         if (nfixed) {
             // columns of binaries fixed to one (needed by the constant direction), then
             // prescribed inputs become identity rows / columns
-            for (int i = lane; i < nz; i += WAVE) {
+            for (int i = lane; i < nz; i += D::kNT) {
                 double a = 0;
                 for (int b = 0; b < nub; b++)
                     if (fx[b] == 1) a += S.Mm[i * nz + nx + nuc + b];
                 S.g[t * nz + i] = a;
             }
             __syncthreads();
-            for (int e = lane; e < nz * nz; e += WAVE) {
+            for (int e = lane; e < nz * nz; e += D::kNT) {
                 const int i = e / nz, j = e - i * nz;
                 const bool fi = i >= nx + nuc && fx[i - nx - nuc] >= 0;
                 const bool fj = j >= nx + nuc && fx[j - nx - nuc] >= 0;
@@ -330,7 +381,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             }
             __syncthreads();
         } else {
-            for (int i = lane; i < nz; i += WAVE) S.g[t * nz + i] = 0.0;
+            for (int i = lane; i < nz; i += D::kNT) S.g[t * nz + i] = 0.0;
         }
         // elimination of the free inputs, pivot order u_0 .. u_{nu-1}
         for (int j = 0; j < nu; j++) {
@@ -349,7 +400,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             // identity block are nonzero in the pivot row (it is unit lower triangular).
             const int nrem = nx + (nu - 1 - j);
             const int ncols = nrem + j + 1;
-            for (int e = lane; e < nrem * ncols; e += WAVE) {
+            for (int e = lane; e < nrem * ncols; e += D::kNT) {
                 const int a = e / ncols, bcol = e - a * ncols;
                 const int i = a < nx ? a : pj + 1 + (a - nx);
                 const double mij = S.Mm[i * nz + pj] * rinv;
@@ -367,15 +418,15 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         __syncthreads();
         // After the sweep: Mm[x][x] = Schur complement, E[x][:] = -M_xu M_uu^{-1} = -Kg',
         // E[u][:] = unit-lower inverse factor, pivots on the diagonal of Mm[u][u].
-        for (int e = lane; e < nx * nx; e += WAVE) {
+        for (int e = lane; e < nx * nx; e += D::kNT) {
             const int i = e / nx, j = e - i * nx;
             if (i >= j) S.Pr[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
         }
-        for (int e = lane; e < nu * nx; e += WAVE) {
+        for (int e = lane; e < nu * nx; e += D::kNT) {
             const int i = e / nx, c = e - i * nx;
             S.Kg[t * nu * nx + e] = -S.E[c * nu + i];
         }
-        for (int e = lane; e < nu * nu; e += WAVE) {
+        for (int e = lane; e < nu * nu; e += D::kNT) {
             const int i = e / nu, j = e - i * nu;
             if (i < j) continue;
             double a = 0;
@@ -400,7 +451,8 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
     const int T = p.T;
     constexpr int NXS = NX * (NX + 1) / 2, NUS = NU * (NU + 1) / 2;
-    for (int e = lane; e < NX * NX; e += WAVE) {
+    if (lane == 0) S.flag[0] = 0;
+    for (int e = lane; e < NX * NX; e += D::kNT) {
         const int i = e / NX, j = e - i * NX;
         if (i >= j) S.Pr[T * NXS + sym(i, j)] = S.PT[e];
     }
@@ -410,13 +462,13 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         const ldsd *Pn = S.Pr + (t + 1) * NXS;
         const ldsi *fx = S.fix + t * NUB;
         // phase 1 (LDS): M = P + C' D C by Gram lists ; PA = Pn [A B]
-        for (int e = lane; e < NE; e += WAVE) {
+        for (int e = lane; e < NE; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             const double a = S.P[i * NZ + j] + gram_entry<D>(p, S, t, e, i, j);
             S.Mm[i * NZ + j] = a;
             S.Mm[j * NZ + i] = a;
         }
-        for (int e = lane; e < NX * NZ; e += WAVE) {
+        for (int e = lane; e < NX * NZ; e += D::kNT) {
             const int i = e / NZ, j = e - i * NZ;
             double a = 0;
 #pragma unroll
@@ -425,7 +477,8 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         }
         __syncthreads();
         FSTAMP(0);
-        // phase 2 (registers): assemble the column, prescribe, eliminate
+        // phase 2 (registers, wave 0 only): assemble the column, prescribe, eliminate
+        if (lane < WAVE) {
         double col[NZ];
         if (lane < NZ) {
 #pragma unroll
@@ -509,23 +562,29 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
 #pragma unroll
             for (int l = 0; l < NU; l++) S.E[(NX + l) * NU + c] = col[NX + l];
         }
+        if (lane == 0) {
+#pragma unroll
+            for (int l = 0; l < NU; l++) S.mv[l] = dinv[l]; // reciprocal pivots for the inverse below
+            if (bad) S.flag[0] = 1;
+        }
+        } // wave 0
         __syncthreads();
         FSTAMP(4);
         // phase 3: M_uu^{-1} = E_u' diag(1/pivot) E_u ; overlaps with the next stage's phase 1
-        for (int e = lane; e < NU * NU; e += WAVE) {
+        for (int e = lane; e < NU * NU; e += D::kNT) {
             const int i = e / NU, j = e - i * NU;
             if (i >= j) {
                 double a = 0;
 #pragma unroll
                 for (int l = 0; l < NU; l++)
-                    if (l >= i) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * dinv[l];
+                    if (l >= i) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * S.mv[l];
                 S.Minv[t * NUS + sym(i, j)] = a;
             }
         }
         FSTAMP(5);
     }
     __syncthreads();
-    return bad ? -1 : 0;
+    return S.flag[0] ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -543,19 +602,19 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     // g = rhs_d + C' e  (column lists)
     // S.g <- (the factorisation's mb, left in S.g, if useb) - (rhs_d + C' e)
-    for (int o = lane; o < T * nz; o += WAVE) {
+    for (int o = lane; o < T * nz; o += D::kNT) {
         const int t = o / nz, j = o - t * nz;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
         S.g[o] = (useb ? S.g[o] : 0.0) - a;
     }
-    for (int j = lane; j < nx; j += WAVE) S.pv[T * nx + j] = -(gsrc ? gs * gsrc[T * nz + j] : 0.0);
+    for (int j = lane; j < nx; j += D::kNT) S.pv[T * nx + j] = -(gsrc ? gs * gsrc[T * nz + j] : 0.0);
     __syncthreads();
     // backward sweep
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *qv = S.pv + (t + 1) * nx;
         if (csrc) {
             const ldsd *Pn = S.Pr + (t + 1) * (nx * (nx + 1) / 2);
-            for (int i = lane; i < nx; i += WAVE) {
+            for (int i = lane; i < nx; i += D::kNT) {
                 double a = S.pv[(t + 1) * nx + i];
                 for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * cs * csrc[t * nx + l];
                 S.q[i] = a;
@@ -563,7 +622,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
             __syncthreads();
             qv = S.q;
         }
-        for (int j = lane; j < nz; j += WAVE) {
+        for (int j = lane; j < nz; j += D::kNT) {
             double a = S.g[t * nz + j];
             for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * qv[l];
             if (j >= nx + nuc) {
@@ -574,7 +633,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
             if (j >= nx) S.mus[t * nu + (j - nx)] = a;
         }
         __syncthreads();
-        for (int i = lane; i < nx; i += WAVE) {
+        for (int i = lane; i < nx; i += D::kNT) {
             double a = S.mv[i];
             for (int l = 0; l < nu; l++) a -= S.Kg[t * nu * nx + l * nx + i] * S.mv[nx + l];
             S.pv[t * nx + i] = a;
@@ -582,18 +641,18 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
         __syncthreads();
     }
     // forward sweep
-    for (int i = lane; i < nx; i += WAVE) dw[i] = usex0 ? S.x0[i] : 0.0;
+    for (int i = lane; i < nx; i += D::kNT) dw[i] = usex0 ? S.x0[i] : 0.0;
     __syncthreads();
     for (int t = 0; t < T; t++) {
         const ldsd *x = dw + t * nz;
-        for (int i = lane; i < nu; i += WAVE) {
+        for (int i = lane; i < nu; i += D::kNT) {
             double a = 0;
             for (int l = 0; l < nx; l++) a += S.Kg[t * nu * nx + i * nx + l] * x[l];
             for (int l = 0; l < nu; l++) a += S.Minv[t * (nu * (nu + 1) / 2) + sym(i, l)] * S.mus[t * nu + l];
             dw[t * nz + nx + i] = -a;
         }
         __syncthreads();
-        for (int i = lane; i < nx; i += WAVE) {
+        for (int i = lane; i < nx; i += D::kNT) {
             double a = csrc ? cs * csrc[t * nx + i] : 0.0;
             for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * dw[t * nz + l];
             dw[(t + 1) * nz + i] = a;
@@ -601,13 +660,13 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
         __syncthreads();
     }
     // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
-    for (int o = lane; o < (T + 1) * nx; o += WAVE) {
+    for (int o = lane; o < (T + 1) * nx; o += D::kNT) {
         const int t = o / nx, i = o - t * nx;
         double a = S.pv[o];
         for (int l = 0; l < nx; l++) a += S.Pr[t * (nx * (nx + 1) / 2) + sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
-    for (int r = lane; r < p.M; r += WAVE) {
+    for (int r = lane; r < p.M; r += D::kNT) {
         const double d = S.D[r];
         if (d != 0.0) { // inactive rows keep e = 0
             int t, lr;
@@ -618,7 +677,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
     const bool own_g = gsrc && gsrc != S.g; // a refinement call passes its residual in S.g (zero there)
-    for (int o = lane; o < T * nub; o += WAVE) {
+    for (int o = lane; o < T * nub; o += D::kNT) {
         const int t = o / nub, b = o - t * nub;
         double a = 0;
         if (S.fix[o] >= 0) {
@@ -648,7 +707,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     const int T = p.T;
     FSTAMP_DECL;
     // S.g <- (mb if useb) - (rhs_d + C' e): the part of the stage gradient the recursion does not touch
-    for (int o = lane; o < T * NZ; o += WAVE) {
+    for (int o = lane; o < T * NZ; o += D::kNT) {
         const int t = o / NZ, j = o - t * NZ;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
         S.g[o] = (useb ? S.g[o] : 0.0) - a;
@@ -660,7 +719,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     }
     __syncthreads();
     FSTAMP(6);
-    {   // backward sweep
+    if (lane < WAVE) { // backward sweep (wave 0)
         double ABcol[NX];
 #pragma unroll
         for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
@@ -691,7 +750,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     __syncthreads();
     FSTAMP(7);
     // M_uu^{-1} m_u for every stage at once
-    for (int o = lane; o < T * NU; o += WAVE) {
+    for (int o = lane; o < T * NU; o += D::kNT) {
         const int t = o / NU, i = o - t * NU;
         double a = 0;
 #pragma unroll
@@ -700,7 +759,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     }
     __syncthreads();
     FSTAMP(8);
-    {   // forward sweep
+    if (lane < WAVE) { // forward sweep (wave 0)
         double ABrow[NZ];
 #pragma unroll
         for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
@@ -729,14 +788,14 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     __syncthreads();
     FSTAMP(9);
     // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
-    for (int o = lane; o < (T + 1) * NX; o += WAVE) {
+    for (int o = lane; o < (T + 1) * NX; o += D::kNT) {
         const int t = o / NX, i = o - t * NX;
         double a = S.pv[o];
 #pragma unroll
         for (int l = 0; l < NX; l++) a += S.Pr[t * (NX * (NX + 1) / 2) + sym(i, l)] * dw[t * NZ + l];
         dlam[o] = -a;
     }
-    for (int r = lane; r < p.M; r += WAVE) {
+    for (int r = lane; r < p.M; r += D::kNT) {
         const double d = S.D[r];
         if (d != 0.0) { // inactive rows keep e = 0
             int t, lr;
@@ -747,7 +806,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
     const bool own_g = gsrc && gsrc != S.g;
-    for (int o = lane; o < T * NUB; o += WAVE) {
+    for (int o = lane; o < T * NUB; o += D::kNT) {
         const int t = o / NUB, b = o - t * NUB;
         double a = 0;
         if (S.fix[o] >= 0) {
@@ -778,10 +837,10 @@ template <class D>
 DEV double lin_obj(const DevProb &p, const Lds &S, int lane, const ldsd *lam, const ldsd *nuf, const ldsd *zrow)
 {
     double a = 0;
-    for (int j = lane; j < D::nx(p); j += WAVE) a += S.x0[j] * lam[j];
-    for (int o = lane; o < p.T * D::nub(p); o += WAVE)
+    for (int j = lane; j < D::nx(p); j += D::kNT) a += S.x0[j] * lam[j];
+    for (int o = lane; o < p.T * D::nub(p); o += D::kNT)
         if (S.fix[o] == 1) a += nuf[o];
-    for (int r = lane; r < p.M; r += WAVE) {
+    for (int r = lane; r < p.M; r += D::kNT) {
         const double v = zrow[r];
         if (v != 0.0) {
             int t, lr;
@@ -789,14 +848,14 @@ DEV double lin_obj(const DevProb &p, const Lds &S, int lane, const ldsd *lam, co
             a += hrow(p, S, lr) * v;
         }
     }
-    return wave_sum(a);
+    return a; // per-thread partial sum: the caller reduces it together with its other sums
 }
 
 template <class D> DEV void set_prescribed(const DevProb &p, const Lds &S, int lane, double tau)
 {
     const int nub = D::nub(p);
-    for (int i = lane; i < D::nx(p); i += WAVE) S.w[i] = S.x0[i] * tau;
-    for (int o = lane; o < p.T * nub; o += WAVE)
+    for (int i = lane; i < D::nx(p); i += D::kNT) S.w[i] = S.x0[i] * tau;
+    for (int o = lane; o < p.T * nub; o += D::kNT)
         if (S.fix[o] >= 0) S.w[(o / nub) * D::nz(p) + D::nx(p) + D::nuc(p) + (o % nub)] = S.fix[o] * tau;
 }
 
@@ -805,7 +864,7 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, n = T * nz + nx;
     double acc = 0;
-    for (int o = lane; o < n; o += WAVE) {
+    for (int o = lane; o < n; o += D::kNT) {
         const int t = o / nz < T ? o / nz : T;
         const int i = o - t * nz, dim = t < T ? nz : nx;
         const ldsd *PP = t < T ? S.P : S.PT;
@@ -823,7 +882,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                   double *trace)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
-    const int nslot = RS > 0 ? RS : p.Mpad / WAVE;
+    const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
     int mact = 0;
     ROWS_BEGIN(k, r)
         int t, lr;
@@ -833,17 +892,17 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         R.s(k, r) = 1.0;
         S.z[r] = on ? 1.0 : 0.0;
     ROWS_END
-    mact = (int)wave_sum((double)mact);
-    for (int i = lane; i < n; i += WAVE) S.w[i] = 0.0;
-    for (int i = lane; i < (T + 1) * nx; i += WAVE) S.lam[i] = 0.0;
-    for (int i = lane; i < T * nub; i += WAVE) S.nuf[i] = 0.0;
+    mact = (int)block_sum<D>((double)mact, S.red, lane);
+    for (int i = lane; i < n; i += D::kNT) S.w[i] = 0.0;
+    for (int i = lane; i < (T + 1) * nx; i += D::kNT) S.lam[i] = 0.0;
+    for (int i = lane; i < T * nub; i += D::kNT) S.nuf[i] = 0.0;
     double tau = 1.0, kap = 1.0;
     __syncthreads();
     set_prescribed<D>(p, S, lane, tau);
     __syncthreads();
     double x0inf = 0;
-    for (int i = lane; i < nx; i += WAVE) x0inf = fmax(x0inf, fabs(S.x0[i]));
-    x0inf = wave_max(x0inf);
+    for (int i = lane; i < nx; i += D::kNT) x0inf = fmax(x0inf, fabs(S.x0[i]));
+    x0inf = block_max<D>(x0inf, S.red, lane);
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
 #ifdef HMPC_STAMPS
@@ -854,7 +913,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         STAMP(7);
         // ---------------- residuals ----------------
         double wPw = 0;
-        for (int o = lane; o < n; o += WAVE) {
+        for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
             const int i = o - t * nz, dim = t < T ? nz : nx;
             const ldsd *PP = t < T ? S.P : S.PT;
@@ -862,9 +921,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             for (int j = 0; j < dim; j++) a += PP[i * dim + j] * S.w[t * nz + j];
             wPw += a * S.w[o];
         }
-        wPw = wave_sum(wPw);
         double rdinf = 0, certinf = 0, fy = 0, winf = 0, yinf = 0;
-        for (int o = lane; o < n; o += WAVE) {
+        for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
             const int j = o - t * nz;
             double a = 0; // E'y + C'z
@@ -889,7 +947,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             winf = fmax(winf, fabs(S.w[o]));
         }
         double rcinf = 0;
-        for (int o = lane; o < T * nx; o += WAVE) {
+        for (int o = lane; o < T * nx; o += D::kNT) {
             const int t = o / nx, i = o - t * nx;
             double a = S.w[(t + 1) * nz + i];
             for (int l = 0; l < nz; l++) a -= S.AB[i * nz + l] * S.w[t * nz + l];
@@ -911,15 +969,18 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             R.rc(k, r) = a;
             rcinf = fmax(rcinf, fabs(a));
         ROWS_END
-        for (int o = lane; o < (T + 1) * nx; o += WAVE) yinf = fmax(yinf, fabs(S.lam[o]));
-        for (int o = lane; o < T * nub; o += WAVE) {
+        for (int o = lane; o < (T + 1) * nx; o += D::kNT) yinf = fmax(yinf, fabs(S.lam[o]));
+        for (int o = lane; o < T * nub; o += D::kNT) {
             yinf = fmax(yinf, fabs(S.nuf[o]));
             if (S.fix[o] == 1) fy += S.nuf[o];
         }
-        for (int j = lane; j < nx; j += WAVE) fy += S.x0[j] * S.lam[j];
-        rdinf = wave_max(rdinf); certinf = wave_max(certinf); winf = wave_max(winf);
-        rcinf = wave_max(rcinf); zinf = wave_max(fmax(zinf, yinf));
-        fy = wave_sum(fy); hz = wave_sum(hz); sz = wave_sum(sz);
+        for (int j = lane; j < nx; j += D::kNT) fy += S.x0[j] * S.lam[j];
+        {
+            double v[9] = {rdinf, certinf, winf, rcinf, fmax(zinf, yinf), fy, hz, sz, wPw};
+            const int op[9] = {1, 1, 1, 1, 1, 0, 0, 0, 0};
+            block_reduce<D, 9>(v, op, S.red, lane);
+            rdinf = v[0]; certinf = v[1]; winf = v[2]; rcinf = v[3]; zinf = v[4]; fy = v[5]; hz = v[6]; sz = v[7]; wPw = v[8];
+        }
         const double rg = wPw / tau + fy + hz + kap;
         const double mu = (sz + tau * kap) / (mact + 1);
         STAMP(0);
@@ -969,11 +1030,16 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         STAMP(3);
         double g1 = 0;
         g1 = wPv<D>(p, S, lane, S.w1);
-        g1 = wave_sum(g1) * 2.0 / tau;
         ROWS_BEGIN(k, r)
             R.z1(k, r) = S.e[r];
         ROWS_END
-        const double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
+        double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
+        {
+            double v[2] = {g1, fyhz1};
+            const int op[2] = {0, 0};
+            block_reduce<D, 2>(v, op, S.red, lane);
+            g1 = v[0] * 2.0 / tau; fyhz1 = v[1];
+        }
         const double den = kap / tau + wPw / (tau * tau) - g1 - fyhz1;
 
         double dtau_a = 0, dkap_a = 0, sigma = 0;
@@ -997,14 +1063,19 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             STAMP(3);
             double g2 = 0;
             g2 = wPv<D>(p, S, lane, S.w2);
-            g2 = wave_sum(g2) * 2.0 / tau;
-            const double fyhz2 = lin_obj<D>(p, S, lane, S.lam2, S.nuf2, S.e);
+            double fyhz2 = lin_obj<D>(p, S, lane, S.lam2, S.nuf2, S.e);
+            {
+                double v[2] = {g2, fyhz2};
+                const int op[2] = {0, 0};
+                block_reduce<D, 2>(v, op, S.red, lane);
+                g2 = v[0] * 2.0 / tau; fyhz2 = v[1];
+            }
             const double dtau = (lin * rg - dkap_rhs / tau + g2 + fyhz2) / den;
             const double dkap = -(dkap_rhs + kap * dtau) / tau;
             // combined direction d = v2 + dtau v1
-            for (int o = lane; o < n; o += WAVE) S.w2[o] += dtau * S.w1[o];
-            for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += dtau * S.lam1[o];
-            for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += dtau * S.nuf1[o];
+            for (int o = lane; o < n; o += D::kNT) S.w2[o] += dtau * S.w1[o];
+            for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += dtau * S.lam1[o];
+            for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += dtau * S.nuf1[o];
             ROWS_BEGIN(k, r)
                 const double v = S.D[r] != 0.0 ? S.e[r] + dtau * R.z1(k, r) : 0.0;
                 S.e[r] = v;
@@ -1014,7 +1085,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             if (pass == 1 && p.refine && mu < 1e-3) { // pays only once D = z/s spans many orders of magnitude
                 // residual of the three linear blocks at the combined direction (x_0 and fixed
                 // binaries are met by construction), then one correction solve
-                for (int o = lane; o < n; o += WAVE) {
+                for (int o = lane; o < n; o += D::kNT) {
                     const int t = o / nz < T ? o / nz : T;
                     const int j = o - t * nz, dim = t < T ? nz : nx;
                     const ldsd *PP = t < T ? S.P : S.PT;
@@ -1031,7 +1102,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     }
                     S.g[o] = a;
                 }
-                for (int o = lane; o < T * nx; o += WAVE) {
+                for (int o = lane; o < T * nx; o += D::kNT) {
                     const int t = o / nx, i = o - t * nx;
                     double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
                     for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * S.w2[t * nz + l];
@@ -1056,9 +1127,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 STAMP(5);
                 kkt_dispatch<D>(p, S, lane, S.g, 1.0, false, S.rdyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
                 STAMP(3);
-                for (int o = lane; o < n; o += WAVE) S.w2[o] += S.w1[o];
-                for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam2[o] += S.lam1[o];
-                for (int o = lane; o < T * nub; o += WAVE) S.nuf2[o] += S.nuf1[o];
+                for (int o = lane; o < n; o += D::kNT) S.w2[o] += S.w1[o];
+                for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += S.lam1[o];
+                for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += S.nuf1[o];
                 ROWS_BEGIN(k, r)
                     if (S.D[r] != 0.0) R.dz(k, r) += S.e[r];
                 ROWS_END
@@ -1078,7 +1149,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     else R.rc(k, r) = ds; // row residual no longer needed this iteration
                 }
             ROWS_END
-            amax = wave_min(amax);
+            amax = block_min<D>(amax, S.red, lane);
             if (pass == 0) {
                 const double aa = fmin(1.0, amax);
                 sigma = (1 - aa) * (1 - aa) * (1 - aa);
@@ -1087,9 +1158,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             } else {
                 const double alpha = fmin(1.0, 0.99 * amax);
                 __syncthreads();
-                for (int o = lane; o < n; o += WAVE) S.w[o] += alpha * S.w2[o];
-                for (int o = lane; o < (T + 1) * nx; o += WAVE) S.lam[o] += alpha * S.lam2[o];
-                for (int o = lane; o < T * nub; o += WAVE) S.nuf[o] += alpha * S.nuf2[o];
+                for (int o = lane; o < n; o += D::kNT) S.w[o] += alpha * S.w2[o];
+                for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] += alpha * S.lam2[o];
+                for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] += alpha * S.nuf2[o];
                 ROWS_BEGIN(k, r)
                     if (S.D[r] != 0.0) {
                         S.z[r] += alpha * R.dz(k, r);
@@ -1121,11 +1192,11 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
 template <class D> DEV double terminal_violation(const DevProb &p, const Lds &S, int lane, double tau)
 {
     double tv = -1e300;
-    for (int k = lane; k < p.nT; k += WAVE) {
+    for (int k = lane; k < p.nT; k += D::kNT) {
         const double a = crow_dot<D>(p, S, p.mreg + k, S.w + (p.T - 1) * D::nz(p)) - p.ht[k] * tau;
         tv = fmax(tv, a / tau);
     }
-    return wave_max(tv);
+    return block_max<D>(tv, S.red, lane);
 }
 
 // Output record in the reference's conventions (subproblem_solution.py:68-168).
@@ -1138,10 +1209,10 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     double scale;
     if (inf) {
         double big = 0;
-        for (int r = lane; r < M; r += WAVE) big = fmax(big, S.z[r]);
-        for (int o = lane; o < (T + 1) * nx; o += WAVE) big = fmax(big, fabs(S.lam[o]));
-        for (int o = lane; o < T * nub; o += WAVE) big = fmax(big, fabs(S.nuf[o]));
-        scale = 1.0 / wave_max(big); // Farkas ray: scale is arbitrary
+        for (int r = lane; r < M; r += D::kNT) big = fmax(big, S.z[r]);
+        for (int o = lane; o < (T + 1) * nx; o += D::kNT) big = fmax(big, fabs(S.lam[o]));
+        for (int o = lane; o < T * nub; o += D::kNT) big = fmax(big, fabs(S.nuf[o]));
+        scale = 1.0 / block_max<D>(big, S.red, lane); // Farkas ray: scale is arbitrary
     } else {
         scale = 1.0 / (tau * p.cs);
     }
@@ -1150,12 +1221,12 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     const int o_mu = (T + 1) * nx, o_lb = o_mu + nmu, o_ub = o_lb + T * nub, o_rho = o_ub + T * nub;
     const int o_sig = o_rho + T * p.nq + p.nqT;
     double farkas = 0;
-    for (int o = lane; o < (T + 1) * nx; o += WAVE) {
+    for (int o = lane; o < (T + 1) * nx; o += D::kNT) {
         const double v = S.lam[o] * scale;
         if (dual) dual[o] = v;
         if (o < nx) farkas -= S.x0[o] * v;
     }
-    for (int r = lane; r < M; r += WAVE) {
+    for (int r = lane; r < M; r += D::kNT) {
         int t, lr;
         row_decode(p, r, t, lr);
         if (lr < p.nc || lr >= p.mreg) { // [F G] rows and terminal-set rows are the reference's mu_t
@@ -1165,7 +1236,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
             farkas -= (hrow(p, S, lr) / sc) * v;
         }
     }
-    for (int o = lane; o < T * nub; o += WAVE) {
+    for (int o = lane; o < T * nub; o += D::kNT) {
         const int t = o / nub, b = o - t * nub;
         double lo, hi;
         if (S.fix[o] < 0) {
@@ -1180,17 +1251,17 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
         }
         if (dual) { dual[o_lb + o] = lo; dual[o_ub + o] = hi; }
     }
-    farkas = wave_sum(farkas);
+    farkas = block_sum<D>(farkas, S.red, lane);
     double cost = 0, dq = 0;
     if (inf) {
-        if (prim) for (int o = lane; o < p.n_primal; o += WAVE) prim[o] = __longlong_as_double(0x7ff8000000000000LL);
-        if (dual) for (int o = o_rho + lane; o < p.n_dual; o += WAVE) dual[o] = 0.0;
+        if (prim) for (int o = lane; o < p.n_primal; o += D::kNT) prim[o] = __longlong_as_double(0x7ff8000000000000LL);
+        if (dual) for (int o = o_rho + lane; o < p.n_dual; o += D::kNT) dual[o] = 0.0;
     } else {
         if (prim) {
-            for (int o = lane; o < (T + 1) * nx; o += WAVE) prim[o] = S.w[(o / nx) * nz + (o % nx)] / tau;
-            for (int o = lane; o < T * nu; o += WAVE) prim[(T + 1) * nx + o] = S.w[(o / nu) * nz + nx + (o % nu)] / tau;
+            for (int o = lane; o < (T + 1) * nx; o += D::kNT) prim[o] = S.w[(o / nx) * nz + (o % nx)] / tau;
+            for (int o = lane; o < T * nu; o += D::kNT) prim[(T + 1) * nx + o] = S.w[(o / nu) * nz + nx + (o % nu)] / tau;
         }
-        for (int o = lane; o < T * p.nq + p.nqT; o += WAVE) {
+        for (int o = lane; o < T * p.nq + p.nqT; o += D::kNT) {
             const int t = (p.nq > 0 && o / p.nq < T) ? o / p.nq : T;
             const int r = o - t * p.nq;
             const double *QQ = t < T ? p.Q : p.QT;
@@ -1200,7 +1271,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
             if (dual) dual[o_rho + o] = 2 * a;
             cost += a * a;
         }
-        for (int o = lane; o < T * p.nr; o += WAVE) {
+        for (int o = lane; o < T * p.nr; o += D::kNT) {
             const int t = o / p.nr, r = o - t * p.nr;
             double a = 0;
             for (int j = 0; j < nu; j++) a += p.R[r * nu + j] * S.w[t * nz + nx + j];
@@ -1208,7 +1279,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
             if (dual) dual[o_sig + o] = 2 * a;
             cost += a * a;
         }
-        cost = wave_sum(cost);
+        cost = block_sum<D>(cost, S.red, lane);
         dq = 4.0 * cost; // sum rho^2 + sigma^2
     }
     if (lane == 0) {
@@ -1218,14 +1289,14 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     }
 }
 
-template <int NX_, int NU_, int NUB_, int RS>
-__global__ void __launch_bounds__(WAVE)
+template <int NX_, int NU_, int NUB_, int RS, int NW>
+__global__ void __launch_bounds__(NW * WAVE)
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef Dims<NX_, NU_, NUB_> D;
-    const int lane = threadIdx.x;
+    typedef Dims<NX_, NU_, NUB_, NW> D;
+    const int lane = threadIdx.x; // thread of the workgroup; wave 0 (lane < 64) runs the recursions
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M, n = T * nz + nx, ne = D::ne(p);
     Lds S;
     {
@@ -1244,31 +1315,32 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + nz * nu + nx * nz;
         S.w2 = take(dir2 > fscr ? dir2 : fscr); S.lam2 = S.w2 + n; S.nuf2 = S.lam2 + (T + 1) * nx;
         S.Mm = S.w2; S.E = S.Mm + nz * nz; S.PA = S.E + nz * nu;
-        S.q = take(nx); S.mv = take(nz);
+        S.q = take(nx); S.mv = take(nz); S.red = take(40);
         S.x0 = take(nx);
         S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
         ldsd *h0 = take(p.mreg), *rval0 = take(p.nnz0), *cval0 = take(p.nnz0), *gval0 = take(p.nng0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
+        S.flag = takei(2);
         S.fix = takei(T * nub);
         S.ei = takei(ne); S.ej = takei(ne);
         ldsi *rptr0 = takei(p.mreg + 1), *rcol0 = takei(p.nnz0), *cptr0 = takei(nz + 1), *crow0 = takei(p.nnz0);
         ldsi *gptr0 = takei(ne + 1), *grow0 = takei(p.nng0);
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
-        for (int i = lane; i < nx * nz; i += WAVE) {
+        for (int i = lane; i < nx * nz; i += D::kNT) {
             const int l = i / nz, j = i - l * nz;
             S.AB[i] = j < nx ? p.A[l * nx + j] : p.B[l * nu + (j - nx)];
         }
-        for (int i = lane; i < nz * nz; i += WAVE) S.P[i] = p.P[i];
-        for (int i = lane; i < nx * nx; i += WAVE) S.PT[i] = p.PT[i];
-        for (int i = lane; i < p.mreg; i += WAVE) h0[i] = g0.h[i];
-        for (int i = lane; i < p.nnz0; i += WAVE) { rval0[i] = g0.rval[i]; cval0[i] = g0.cval[i]; rcol0[i] = g0.rcol[i]; crow0[i] = g0.crow[i]; }
-        for (int i = lane; i < p.nng0; i += WAVE) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
-        for (int i = lane; i < p.mreg + 1; i += WAVE) rptr0[i] = g0.rptr[i];
-        for (int i = lane; i < nz + 1; i += WAVE) cptr0[i] = g0.cptr[i];
-        for (int i = lane; i < ne + 1; i += WAVE) gptr0[i] = g0.gptr[i];
-        for (int i = lane; i < ne; i += WAVE) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
+        for (int i = lane; i < nz * nz; i += D::kNT) S.P[i] = p.P[i];
+        for (int i = lane; i < nx * nx; i += D::kNT) S.PT[i] = p.PT[i];
+        for (int i = lane; i < p.mreg; i += D::kNT) h0[i] = g0.h[i];
+        for (int i = lane; i < p.nnz0; i += D::kNT) { rval0[i] = g0.rval[i]; cval0[i] = g0.cval[i]; rcol0[i] = g0.rcol[i]; crow0[i] = g0.crow[i]; }
+        for (int i = lane; i < p.nng0; i += D::kNT) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
+        for (int i = lane; i < p.mreg + 1; i += D::kNT) rptr0[i] = g0.rptr[i];
+        for (int i = lane; i < nz + 1; i += D::kNT) cptr0[i] = g0.cptr[i];
+        for (int i = lane; i < ne + 1; i += D::kNT) gptr0[i] = g0.gptr[i];
+        for (int i = lane; i < ne; i += D::kNT) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
         S.term_on = 0;
     }
@@ -1276,8 +1348,8 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     R.bind(rows_ws + (size_t)blockIdx.x * 5 * p.Mpad, p.Mpad);
     for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
         __syncthreads();
-        for (int o = lane; o < T * nub; o += WAVE) S.fix[o] = fixg[(size_t)qp * T * nub + o];
-        for (int i = lane; i < nx; i += WAVE) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
+        for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
+        for (int i = lane; i < nx; i += D::kNT) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
         __syncthreads();
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
         double tau = 1.0;
@@ -1304,21 +1376,42 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
 }
 
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
-// nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries) with the
-// row slots that cover their horizons, and the generic run-time-sized kernel for everything else.
+// nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries), with the
+// row slots of their horizons and 1 / 2 / 4 waves per node, and the generic run-time-sized kernel.
 typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *);
-static hmpc_kernel_t hmpc_pick_kernel(const DevProb &p)
+struct hmpc_kernel_choice {
+    hmpc_kernel_t fn;
+    int waves;
+};
+// Waves per node: measured on MI355X (cart-pole N=20) one wave per node gives the best throughput
+// once every CU holds its three nodes (221 k QP/s at 4096 nodes vs 184 k / 138 k with 2 / 4 waves),
+// while small frontiers finish sooner with the parallel phases spread over more waves (77 nodes:
+// 4.06 / 3.12 / 2.80 ms).  HMPC_WAVES overrides.
+static int hmpc_waves_for(int B, int resident_nodes)
 {
-    const int slots = p.Mpad / WAVE;
-    if (getenv("HMPC_FORCE_GENERIC")) return hmpc_qp_kernel<0, 0, 0, 0>;
-    if (p.nx == 4 && p.nu == 7 && p.nub == 4) {
-        if (slots <= 8) return hmpc_qp_kernel<4, 7, 4, 8>;    // N = 10 (462 rows)
-        if (slots <= 13) return hmpc_qp_kernel<4, 7, 4, 13>;  // N = 20 (822 rows)
-        return hmpc_qp_kernel<4, 7, 4, 0>;
+    if (const char *e = getenv("HMPC_WAVES")) {
+        const int nw = atoi(e);
+        if (nw == 1 || nw == 2 || nw == 4) return nw;
     }
-    if (p.nx == 4 && p.nu == 4 && p.nub == 2) {
-        if (slots <= 15) return hmpc_qp_kernel<4, 4, 2, 15>;  // T = 40 (928 rows)
-        return hmpc_qp_kernel<4, 4, 2, 0>;
+    if (B <= resident_nodes / 3) return 4;
+    if (B <= 2 * resident_nodes) return 2;
+    return 1;
+}
+static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
+{
+    const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr;
+    const int slots = (p.M + nw * WAVE - 1) / (nw * WAVE);
+    if (!generic && p.nx == 4 && p.nu == 7 && p.nub == 4) {
+        if (nw == 1) return {slots <= 8 ? hmpc_qp_kernel<4, 7, 4, 8, 1> : slots <= 13 ? hmpc_qp_kernel<4, 7, 4, 13, 1> : hmpc_qp_kernel<4, 7, 4, 0, 1>, 1};
+        if (nw == 2) return {slots <= 4 ? hmpc_qp_kernel<4, 7, 4, 4, 2> : slots <= 7 ? hmpc_qp_kernel<4, 7, 4, 7, 2> : slots <= 13 ? hmpc_qp_kernel<4, 7, 4, 13, 2> : hmpc_qp_kernel<4, 7, 4, 0, 2>, 2};
+        return {slots <= 4 ? hmpc_qp_kernel<4, 7, 4, 4, 4> : slots <= 7 ? hmpc_qp_kernel<4, 7, 4, 7, 4> : hmpc_qp_kernel<4, 7, 4, 0, 4>, 4};
     }
-    return hmpc_qp_kernel<0, 0, 0, 0>;
+    if (!generic && p.nx == 4 && p.nu == 4 && p.nub == 2) {
+        if (nw == 1) return {hmpc_qp_kernel<4, 4, 2, 0, 1>, 1};
+        if (nw == 2) return {slots <= 8 ? hmpc_qp_kernel<4, 4, 2, 8, 2> : hmpc_qp_kernel<4, 4, 2, 0, 2>, 2};
+        return {slots <= 4 ? hmpc_qp_kernel<4, 4, 2, 4, 4> : hmpc_qp_kernel<4, 4, 2, 0, 4>, 4};
+    }
+    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 1>, 1};
+    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 2>, 2};
+    return {hmpc_qp_kernel<0, 0, 0, 0, 4>, 4};
 }
