@@ -198,3 +198,20 @@ def test_other_problem_shapes_and_size_limit():
     big = HybridModelPredictiveController(mld, 30, objective, None, backend=_NoBackend())
     with pytest.raises(RuntimeError, match='LDS'):
         HipBatchedQP(big.problem_data())
+
+
+def test_lockstep_closed_loops_on_gpu():
+    # many closed loops in lockstep; the GPU walk must be the oracle's walk
+    from warm_start_hmpc_amd.batched import BatchedMPC
+    x_max = load_fixture('cart_pole_with_walls')['x_max']
+    runs = {}
+    for name in ('hip', 'oracle'):
+        ctrl = make_controller('cart_pole_with_walls', backend=name, **({'threads': 8} if name == 'oracle' else {}))
+        runs[name] = BatchedMPC(ctrl).closed_loop(X0, n_steps=4, e_sd=0.003, seeds=(0, 1, 2, 3), x_max=x_max,
+                                                  frontier_width=8, cold_too=True)
+    a, b = runs['hip'], runs['oracle']
+    assert a['steps'] == b['steps'] == 16
+    for k in range(4):
+        np.testing.assert_allclose(a['costs'][k], b['costs'][k], rtol=1e-6)
+        assert a['len_ws'][k][0] == 77
+        assert max(a['nodes_ws'][k][1:]) <= 60 and min(a['nodes_cs'][k]) >= 150
