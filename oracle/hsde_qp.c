@@ -428,6 +428,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
 
     int status = ST_MAXITER, it = 0, extra_done = 0;
     const int extra = 1;
+    double last_alpha = 0, last_dtau = 0, last_dkap = 0;
     double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
     double x0inf = vmaxabs(x0, nx);
     (void)hinf;
@@ -480,14 +481,26 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         double pobj = 0.5 * wPw / (tau * tau), dob = -0.5 * wPw / (tau * tau) - (fy + hz) / tau;
         double gap = fabs(pobj - dob);
         if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e pobj %.6e eta %.3e\n", it, tau, kap, mu, rcinf / tau, rdinf / tau, gap, pobj, -(fy + hz));
-        if (rcinf / tau <= tol * (1 + winf + x0inf) && rdinf / tau <= tol * (1 + zinf) && gap <= tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
-            /* the test is met: take `extra` more iterations (convergence is superlinear here, so
-             * two implementations that cross the threshold one iteration apart still agree) */
+        /* once the test has been met, the extra iteration is accepted at 100 x tol: it sits at the
+         * precision floor of the linear algebra and must not be asked to pass 1e-8 again */
+        const double tl = extra_done ? 100.0 * tol : tol;
+        if (rcinf / tau <= tl * (1 + winf + x0inf) && rdinf / tau <= tl * (1 + zinf) && gap <= tl * (1 + fmin(fabs(pobj), fabs(dob)))) {
+            /* the test is met: take one more iteration (convergence is superlinear here, so two
+             * implementations that cross the threshold one iteration apart still agree), unless the
+             * iterate is already far beyond the tolerance (mu < 1e-11: nothing to gain, and the linear
+             * algebra is at its limit there) */
             status = ST_OPTIMAL;
-            if (extra_done >= extra || it == max_iter) break;
+            if (extra_done >= extra || it == max_iter || mu < 1e-11) break;
             extra_done++;
         } else if (status == ST_OPTIMAL) {
-            status = ST_MAXITER; /* an extra iteration left the tolerance again: keep iterating */
+            /* the extra step made things worse (precision floor): undo it -- the direction is still in
+             * the "2" arrays -- and return the iterate that met the test */
+            for (int i = 0; i < n; i++) k->w[i] -= last_alpha * k->w2[i];
+            for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] -= last_alpha * k->lam2[i];
+            for (int i = 0; i < T * nub; i++) k->nuf[i] -= last_alpha * k->nuf2[i];
+            for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] -= last_alpha * k->z2[r]; k->s[r] -= last_alpha * k->rhs_c[r]; }
+            tau -= last_alpha * last_dtau; kap -= last_alpha * last_dkap;
+            break;
         }
         {   /* Farkas: E'y + C'z = rd - Pw, -(f'y + h'z) > 0 */
             double eta = -(fy + hz), cert = 0;
@@ -495,7 +508,9 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      cert %.3e eta %.3e zinf %.3e raw rd %.3e rc %.3e\n", cert, eta, zinf * tau, rdinf, rcinf);
             /* (a) clean proof; (b) tau has collapsed against kappa: in exact arithmetic that alone
              * means "no optimum", and the proof is as accurate as double precision allows */
-            if (eta > 0 && (cert <= tol_inf * eta || (tau <= 1e-8 * kap && cert <= 1e-3 * eta))) { status = ST_INFEASIBLE; break; }
+            /* (c) tau has vanished (ten orders below kappa): the node is infeasible by less than any
+             * certificate can resolve in double precision; report it with the multipliers at hand */
+            if (eta > 0 && (cert <= tol_inf * eta || (tau <= 1e-8 * kap && cert <= 1e-3 * eta) || tau <= 1e-10 * kap)) { status = ST_INFEASIBLE; break; }
         }
         if (it == max_iter) break;
 
@@ -582,6 +597,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
                 for (int i = 0; i < T * nub; i++) k->nuf[i] += alpha * k->nuf2[i];
                 for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] += alpha * k->z2[r]; k->s[r] += alpha * k->rhs_c[r]; }
                 tau += alpha * dtau; kap += alpha * dkap;
+                last_alpha = alpha; last_dtau = dtau; last_dkap = dkap;
                 for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
                 for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
             }

@@ -905,6 +905,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
     x0inf = block_max<D>(x0inf, S.red, lane);
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
+    double last_alpha = 0, last_dtau = 0, last_dkap = 0;
 #ifdef HMPC_STAMPS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
     long long facc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -992,17 +993,37 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             double *tr = trace + it * 8;
             tr[0] = tau; tr[1] = kap; tr[2] = mu; tr[3] = rcinf / tau; tr[4] = rdinf / tau; tr[5] = gap; tr[6] = eta; tr[7] = certinf;
         }
-        if (rcinf / tau <= p.tol * (1 + winf / tau + x0inf) && rdinf / tau <= p.tol * (1 + zinf / tau) &&
-            gap <= p.tol * (1 + fmin(fabs(pobj), fabs(dob)))) {
+        // once the test has been met, the extra iteration is accepted at 100 x tol: it sits at the
+        // precision floor of the linear algebra and must not be asked to pass 1e-8 again
+        const double tl = extra_done ? 100.0 * p.tol : p.tol;
+        if (rcinf / tau <= tl * (1 + winf / tau + x0inf) && rdinf / tau <= tl * (1 + zinf / tau) &&
+            gap <= tl * (1 + fmin(fabs(pobj), fabs(dob)))) {
             // the test is met: one more iteration (convergence is superlinear here, so the CPU
-            // oracle and this kernel agree even if they cross the threshold an iteration apart)
+            // oracle and this kernel agree even if they cross the threshold an iteration apart),
+            // unless the iterate is already far beyond the tolerance (mu < 1e-11)
             status = HMPC_OPTIMAL;
-            if (extra_done >= 1 || it == p.max_iter) break;
+            if (extra_done >= 1 || it == p.max_iter || mu < 1e-11) break;
             extra_done++;
         } else if (status == HMPC_OPTIMAL) {
-            status = HMPC_MAXITER; // the extra iteration left the tolerance again: keep iterating
+            // the extra step made things worse (precision floor): undo it -- the direction is still
+            // in place -- and return the iterate that met the test
+            for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
+            for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
+            for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
+            ROWS_BEGIN(k, r)
+                if (S.D[r] != 0.0) {
+                    S.z[r] -= last_alpha * R.dz(k, r);
+                    R.s(k, r) -= last_alpha * R.prod(k, r);
+                }
+            ROWS_END
+            tau -= last_alpha * last_dtau;
+            kap -= last_alpha * last_dkap;
+            __syncthreads();
+            break;
         }
-        if (eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
+        // third clause: tau has vanished (ten orders below kappa) -- infeasible by less than a certificate
+        // can resolve in double precision; reported with the multipliers at hand
+        if (eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta) || tau <= 1e-10 * kap)) {
             status = HMPC_INFEASIBLE;
             break;
         }
@@ -1146,7 +1167,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     if (dz < 0) amax = fmin(amax, -zr / dz);
                     if (ds < 0) amax = fmin(amax, -sr / ds);
                     if (pass == 0) R.prod(k, r) = ds * dz;
-                    else R.rc(k, r) = ds; // row residual no longer needed this iteration
+                    else R.prod(k, r) = ds; // the affine product is consumed: keep the slack step here (also for an undo)
                 }
             ROWS_END
             amax = block_min<D>(amax, S.red, lane);
@@ -1164,11 +1185,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 ROWS_BEGIN(k, r)
                     if (S.D[r] != 0.0) {
                         S.z[r] += alpha * R.dz(k, r);
-                        R.s(k, r) += alpha * R.rc(k, r);
+                        R.s(k, r) += alpha * R.prod(k, r);
                     }
                 ROWS_END
                 tau += alpha * dtau;
                 kap += alpha * dkap;
+                last_alpha = alpha; last_dtau = dtau; last_dkap = dkap;
                 __syncthreads();
                 set_prescribed<D>(p, S, lane, tau);
                 __syncthreads();

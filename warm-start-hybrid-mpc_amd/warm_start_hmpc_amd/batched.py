@@ -131,6 +131,10 @@ class BatchedMPC(object):
             t_solver += res['time']
             rounds += 1
             if np.any(res['status'] > 1):
+                import os
+                if os.environ.get('HMPC_DUMP_FAIL'):
+                    bad = np.flatnonzero(res['status'] > 1)
+                    np.savez(os.environ['HMPC_DUMP_FAIL'], x0=x0[bad], fix=fix[bad], status=res['status'][bad], iters=res['iters'][bad])
                 raise RuntimeError('QP solver did not converge on %d nodes' % int((res['status'] > 1).sum()))
             o = 0
             for tr, p in zip(trees, picks):
