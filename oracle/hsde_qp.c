@@ -52,6 +52,7 @@
 #define ST_NUMERICAL 3
 /* iterative refinement pays only near the end, where D = z/s spans many orders of magnitude */
 #define REFINE_MU 1e-3
+#define REFINE_MU2 1e-7
 
 typedef struct {
     int nx, nu, nub, nuc, nz, T, nc, ncL, mreg, mlast, M, nq, nr, nqT;
@@ -427,7 +428,6 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
     for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
 
     int status = ST_MAXITER, it = 0, extra_done = 0;
-    const int extra = 1;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
     double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
     double x0inf = vmaxabs(x0, nx);
@@ -481,26 +481,33 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         double pobj = 0.5 * wPw / (tau * tau), dob = -0.5 * wPw / (tau * tau) - (fy + hz) / tau;
         double gap = fabs(pobj - dob);
         if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "it %3d tau %.3e kap %.3e mu %.3e rp %.3e rd %.3e gap %.3e pobj %.6e eta %.3e\n", it, tau, kap, mu, rcinf / tau, rdinf / tau, gap, pobj, -(fy + hz));
-        /* once the test has been met, the extra iteration is accepted at 100 x tol: it sits at the
-         * precision floor of the linear algebra and must not be asked to pass 1e-8 again */
-        const double tl = extra_done ? 100.0 * tol : tol;
-        if (rcinf / tau <= tl * (1 + winf + x0inf) && rdinf / tau <= tl * (1 + zinf) && gap <= tl * (1 + fmin(fabs(pobj), fabs(dob)))) {
-            /* the test is met: take one more iteration (convergence is superlinear here, so two
-             * implementations that cross the threshold one iteration apart still agree), unless the
-             * iterate is already far beyond the tolerance (mu < 1e-11: nothing to gain, and the linear
-             * algebra is at its limit there) */
-            status = ST_OPTIMAL;
-            if (extra_done >= extra || it == max_iter || mu < 1e-11) break;
-            extra_done++;
-        } else if (status == ST_OPTIMAL) {
-            /* the extra step made things worse (precision floor): undo it -- the direction is still in
-             * the "2" arrays -- and return the iterate that met the test */
-            for (int i = 0; i < n; i++) k->w[i] -= last_alpha * k->w2[i];
-            for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] -= last_alpha * k->lam2[i];
-            for (int i = 0; i < T * nub; i++) k->nuf[i] -= last_alpha * k->nuf2[i];
-            for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] -= last_alpha * k->z2[r]; k->s[r] -= last_alpha * k->rhs_c[r]; }
-            tau -= last_alpha * last_dtau; kap -= last_alpha * last_dkap;
-            break;
+        /* Two levels (as in Ipopt's acceptable / desired tolerances).  ACCEPTABLE: scaled residuals and
+         * gap <= tol.  DESIRED: acceptable and gap, dual residual <= 1e-2 tol -- they bound the suboptimality, and
+         * with the curvature of this cost a 1e-8 gap still leaves ~2e-5 in the trajectory; two
+         * implementations that stop an iteration apart must agree to 1e-5.  Once an acceptable iterate
+         * exists, up to 3 more iterations are spent on the desired level; if one of them is worse
+         * (precision floor of the linear algebra) it is undone and the acceptable iterate returned. */
+        {
+            const double gtol = tol * (1 + fmin(fabs(pobj), fabs(dob)));
+            const int acceptable = rcinf / tau <= tol * (1 + winf + x0inf) && rdinf / tau <= tol * (1 + zinf) && gap <= gtol;
+            if (acceptable) {
+                status = ST_OPTIMAL;
+                if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tol * (1 + zinf)) || extra_done >= 3 || it == max_iter) break;
+                extra_done++;
+            } else if (status != ST_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * tol * (1 + winf + x0inf) &&
+                       rdinf / tau <= 100 * tol * (1 + zinf) && gap <= 100 * gtol) {
+                /* the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex
+                 * code's default): nothing more can be gained on an interior-free node */
+                status = ST_OPTIMAL;
+                break;
+            } else if (status == ST_OPTIMAL) {
+                for (int i = 0; i < n; i++) k->w[i] -= last_alpha * k->w2[i];
+                for (int i = 0; i < (T + 1) * nx; i++) k->lam[i] -= last_alpha * k->lam2[i];
+                for (int i = 0; i < T * nub; i++) k->nuf[i] -= last_alpha * k->nuf2[i];
+                for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] -= last_alpha * k->z2[r]; k->s[r] -= last_alpha * k->rhs_c[r]; }
+                tau -= last_alpha * last_dtau; kap -= last_alpha * last_dkap;
+                break;
+            }
         }
         {   /* Farkas: E'y + C'z = rd - Pw, -(f'y + h'z) > 0 */
             double eta = -(fy + hz), cert = 0;
@@ -562,9 +569,12 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             for (int i = 0; i < (T + 1) * nx; i++) k->lam2[i] += dtau * k->lam1[i];
             for (int i = 0; i < T * nub; i++) k->nuf2[i] += dtau * k->nuf1[i];
             for (int r = 0; r < M; r++) k->z2[r] = k->act[r] ? k->z2[r] + dtau * k->z1[r] : 0.0;
-            if (pass == 1 && refine && mu < REFINE_MU) {
-                /* one step of iterative refinement against the three linear blocks of the
-                 * Newton system at this dtau:  K d = rhs2 + dtau rhs1                      */
+            /* iterative refinement against the three linear blocks of the Newton system at this dtau,
+             * K d = rhs2 + dtau rhs1: one step once mu < 1e-3, two once mu < 1e-7 (one step squares the
+             * relative error of a solve, and the stage cost's small curvature needs the dual residual
+             * well below the stopping tolerance for the trajectory to be accurate to 1e-5) */
+            const int nref = (pass == 1 && refine) ? (mu < REFINE_MU2 ? 2 : mu < REFINE_MU ? 1 : 0) : 0;
+            for (int rf = 0; rf < nref; rf++) {
                 kkt_residual(p, k, fix, sd, sc, k->rhs_c, dtau, k->w2, k->lam2, k->nuf2, k->z2, k->ed, k->edyn, k->ec);
                 kkt_solve(p, k, fix, k->ed, NULL, k->edyn, 0, k->ec, k->w1, k->lam1, k->nuf1, k->z1); /* v1 no longer needed */
                 for (int i = 0; i < n; i++) k->w2[i] += k->w1[i];

@@ -44,12 +44,12 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
     size_t d = 0, i = 0;
-    const size_t nus = nu * (nu + 1) / 2, nxs = nx * (nx + 1) / 2;
-    const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nz * nu + nx * nz;
+    const size_t nxs = nx * (nx + 1) / 2, lms = (nx + nu) * nu;
+    const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
     d += dir;                                                             // w lam nuf
-    d += 3 * M;                                                           // z D e
-    d += T * nus + T * nu * nx + (T + 1) * nxs + T * nu;                  // Minv Kg Pr mus
-    d += n + T * nx + n + (T + 1) * nx;                                   // rd rdyn g pv
+    d += M;                                                               // e (row vector: z / D / D.*rhs / dz in turn)
+    d += T * lms + T * nu + (T + 1) * nxs + T * nu;                       // Lm dinv Pr mus
+    d += n + 2 * T * nx + n + (T + 1) * nx;                               // rd rdyn edyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
     d += nx + nz + 40;                                                    // q mv red
     d += nx;                                                              // x0

@@ -140,11 +140,12 @@ struct Lists {
 typedef Lists<const ldsi *, const ldsd *> ListsL;
 
 struct Lds {
-    ldsd *w, *lam, *nuf, *z, *D, *e;
-    ldsd *Minv, *Kg, *Pr, *mus;   // Minv and Pr: packed lower triangles per stage
-    ldsd *rd, *rdyn, *g, *pv;
+    ldsd *w, *lam, *nuf;
+    ldsd *e; // the one row-indexed LDS vector: in turn z (for C'z), D (for the Gram phase), D.*rhs and dz
+    ldsd *Lm, *dinv, *Pr, *mus;   // elimination multipliers, reciprocal pivots, cost-to-go (packed), L_u^{-1} m_u
+    ldsd *rd, *rdyn, *edyn, *g, *pv;
     ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
-    ldsd *Mm, *E, *PA, *q, *mv;
+    ldsd *Mm, *PA, *q, *mv;
     ldsd *red;         // exchange buffer of the workgroup reductions
     ldsi *flag;        // wave 0 -> workgroup: factorisation failed
     ldsd *x0;
@@ -170,29 +171,31 @@ struct Dims {
 };
 
 // Per-row values that only the owning lane touches (row r <-> lane r % 64, slot k = r / 64):
-// slack s, row residual rc, constant-direction step z1, combined step dz, affine product prod.
+// slack s, multiplier z, barrier weight D = z/s (0 on inactive rows), combined step dz, affine
+// product / slack step prod.  Row residuals and the constant direction's dz are recomputed from
+// the stage vectors when needed (a sparse row dot each) instead of being stored.
 // RS > 0: RS slots per lane, kept in registers (every loop over slots is fully unrolled so the
 // arrays are statically indexed).  RS == 0: run-time number of slots, kept in a per-workgroup slab
 // of global memory (coalesced, L2 resident) -- the generic kernel.
 template <int RS>
 struct Rows {
-    double s_[RS], rc_[RS], z1_[RS], dz_[RS], prod_[RS];
+    double s_[RS], z_[RS], D_[RS], dz_[RS], prod_[RS];
     DEV double &s(int k, int) { return s_[k]; }
-    DEV double &rc(int k, int) { return rc_[k]; }
-    DEV double &z1(int k, int) { return z1_[k]; }
+    DEV double &z(int k, int) { return z_[k]; }
+    DEV double &D(int k, int) { return D_[k]; }
     DEV double &dz(int k, int) { return dz_[k]; }
     DEV double &prod(int k, int) { return prod_[k]; }
     DEV void bind(double *, int) {}
 };
 template <>
 struct Rows<0> {
-    double *__restrict__ s_, *__restrict__ rc_, *__restrict__ z1_, *__restrict__ dz_, *__restrict__ prod_;
+    double *__restrict__ s_, *__restrict__ z_, *__restrict__ D_, *__restrict__ dz_, *__restrict__ prod_;
     DEV double &s(int, int r) { return s_[r]; }
-    DEV double &rc(int, int r) { return rc_[r]; }
-    DEV double &z1(int, int r) { return z1_[r]; }
+    DEV double &z(int, int r) { return z_[r]; }
+    DEV double &D(int, int r) { return D_[r]; }
     DEV double &dz(int, int r) { return dz_[r]; }
     DEV double &prod(int, int r) { return prod_[r]; }
-    DEV void bind(double *base, int Mpad) { s_ = base; rc_ = base + Mpad; z1_ = base + 2 * Mpad; dz_ = base + 3 * Mpad; prod_ = base + 4 * Mpad; }
+    DEV void bind(double *base, int Mpad) { s_ = base; z_ = base + Mpad; D_ = base + 2 * Mpad; dz_ = base + 3 * Mpad; prod_ = base + 4 * Mpad; }
 };
 // loop over the rows of this lane: slot k, row r
 #define ROWS_BEGIN(k, r)                                   \
@@ -294,10 +297,10 @@ DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? S
 // (C' D C)(i, j) of stage t: Gram lists of the stage rows, plus the dense terminal block if active
 template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, int e, int i, int j)
 {
-    double a = gram(S.L0, e, S.D + t * p.mreg);
+    double a = gram(S.L0, e, S.e + t * p.mreg); // S.e holds D during the factorisation
     if (S.term_on && t == p.T - 1) {
         const int nz = D::nz(p);
-        const ldsd *Dt = S.D + p.Toff;
+        const ldsd *Dt = S.e + p.Toff;
         double a0 = 0, a1 = 0;
         int k = 0;
         for (; k + 2 <= p.nT; k += 2) {
@@ -311,21 +314,31 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Riccati factorisation of Phi_t = P + C_t' D C_t.  Per stage it leaves in LDS
-//   Kg   = M_uu^{-1} M_ux        (nu x nx, feedback gain)
-//   Minv = M_uu^{-1}             (nu x nu)
-//   Pr_t = Schur complement      (nx x nx, cost-to-go Hessian)
-//   mb   = sum of the columns of M that belong to binaries fixed to one
-// with M = Phi_t + [A B]' Pr_{t+1} [A B] and the rows / columns of fixed binaries replaced by
-// identity (they are prescribed, not optimised).  Elimination runs on the symmetric matrix in
-// (u, x) order, one rank-one update and one barrier per free input (a fixed binary is decoupled
-// and its pivot is skipped); carrying an identity block through the same row operations yields
-// the inverse and the gain without any triangular substitution.
+// Riccati factorisation of Phi_t = P + C_t' D C_t.  For every stage, backwards in time,
+//   M = Phi_t + [A B]' P_{t+1} [A B]
+// is reduced by eliminating its inputs (pivot order u_0 .. u_{nu-1}; the fixed binaries are
+// prescribed: identity rows / columns, unit pivots, skipped).  What is kept per stage is the LDL'
+// factor in the form the solves need:
+//   Lm   : elimination multipliers -- rows of the states ("L_x") and of the inputs ("L_u", strictly
+//          lower triangular), one dense (nx + nu) x nu block
+//   dinv : reciprocal pivots
+//   P_t  : Schur complement = cost-to-go Hessian (packed lower triangle)
+//   mb   : sum of the columns of M of binaries fixed to one, handed to the next solve in S.g
+// A solve applies the same row operations to its vector (forward substitution) and a back
+// substitution with L_u'.  Explicit inverses (M_uu^{-1}, gains) are NOT formed: they are not backward
+// stable and break the iteration once D = z/s spans ~24 orders of magnitude (mu ~ 1e-12); this was
+// observed on the GPU and reproduced on the CPU before this form was adopted.
 // ---------------------------------------------------------------------------------------------
+// dense (nx + nu) x nu block per stage, zeros where a row is not below its pivot: a lane's row is nu
+// contiguous doubles
+#define LM_STAGE(nx, nu) (((nx) + (nu)) * (nu))
+#define LM_X(nx, nu, x, j) ((x) * (nu) + (j))          /* state row x, pivot j  */
+#define LM_U(nx, nu, i, j) (((nx) + (i)) * (nu) + (j)) /* input row i, pivot j  */
+
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
-    const int nxs = nx * (nx + 1) / 2, nus = nu * (nu + 1) / 2;
+    const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     for (int e = lane; e < nx * nx; e += D::kNT) {
         const int i = e / nx, j = e - i * nx;
         if (i >= j) S.Pr[T * nxs + sym(i, j)] = S.PT[e];
@@ -335,9 +348,10 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *Pn = S.Pr + (t + 1) * nxs;
         const ldsi *fx = S.fix + t * nub;
+        ldsd *Lm = S.Lm + t * lms;
         int nfixed = 0;
         for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
-        // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B] ; E = identity block on the inputs
+        // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
         for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             const double a = S.P[i * nz + j] + gram_entry<D>(p, S, t, e, i, j);
@@ -350,10 +364,6 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * S.AB[l * nz + j];
             S.PA[e] = a;
         }
-        for (int e = lane; e < nz * nu; e += D::kNT) {
-            const int i = e / nu, c = e - i * nu;
-            S.E[e] = (i == nx + c) ? 1.0 : 0.0;
-        }
         __syncthreads();
         for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
@@ -363,9 +373,8 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             S.Mm[j * nz + i] = a;
         }
         __syncthreads();
+        for (int e = lane; e < lms; e += D::kNT) Lm[e] = 0.0;
         if (nfixed) {
-            // columns of binaries fixed to one (needed by the constant direction), then
-            // prescribed inputs become identity rows / columns
             for (int i = lane; i < nz; i += D::kNT) {
                 double a = 0;
                 for (int b = 0; b < nub; b++)
@@ -382,11 +391,11 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             __syncthreads();
         } else {
             for (int i = lane; i < nz; i += D::kNT) S.g[t * nz + i] = 0.0;
+            __syncthreads();
         }
-        // elimination of the free inputs, pivot order u_0 .. u_{nu-1}
         for (int j = 0; j < nu; j++) {
-            if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot
-                if (lane == 0) S.mv[j] = 1.0;
+            if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot: the solves skip it as well
+                if (lane == 0) S.dinv[t * nu + j] = 1.0;
                 continue;
             }
             const int pj = nx + j;
@@ -394,44 +403,25 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             if (!(d > 0.0)) bad = 1;
             double rinv = __builtin_amdgcn_rcp(d);
             rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
-            // rows still to be reduced: all states and the inputs after j.  In place: an entry is
-            // read and written by its own lane only; the pivot row and column, which every lane
-            // reads, are not part of the trailing block.  Only columns c <= j of the carried
-            // identity block are nonzero in the pivot row (it is unit lower triangular).
+            // rows still to be reduced: all states and the inputs after j.  In place: an entry is read
+            // and written by its own thread only; the pivot row and column, which every thread reads,
+            // are not part of the trailing block.  The thread of the first trailing column keeps the
+            // row's multiplier.
             const int nrem = nx + (nu - 1 - j);
-            const int ncols = nrem + j + 1;
-            for (int e = lane; e < nrem * ncols; e += D::kNT) {
-                const int a = e / ncols, bcol = e - a * ncols;
+            for (int e = lane; e < nrem * nrem; e += D::kNT) {
+                const int a = e / nrem, bcol = e - a * nrem;
                 const int i = a < nx ? a : pj + 1 + (a - nx);
+                const int k = bcol < nx ? bcol : pj + 1 + (bcol - nx);
                 const double mij = S.Mm[i * nz + pj] * rinv;
-                if (bcol < nrem) {
-                    const int k = bcol < nx ? bcol : pj + 1 + (bcol - nx);
-                    S.Mm[i * nz + k] -= mij * S.Mm[pj * nz + k];
-                } else {
-                    const int c = bcol - nrem;
-                    S.E[i * nu + c] -= mij * S.E[pj * nu + c];
-                }
+                S.Mm[i * nz + k] -= mij * S.Mm[pj * nz + k];
+                if (bcol == 0) Lm[a < nx ? LM_X(nx, nu, a, j) : LM_U(nx, nu, i - nx, j)] = mij;
             }
-            if (lane == 0) S.mv[j] = rinv; // reciprocal pivots for the inverse below
+            if (lane == 0) S.dinv[t * nu + j] = rinv;
             __syncthreads();
         }
-        __syncthreads();
-        // After the sweep: Mm[x][x] = Schur complement, E[x][:] = -M_xu M_uu^{-1} = -Kg',
-        // E[u][:] = unit-lower inverse factor, pivots on the diagonal of Mm[u][u].
         for (int e = lane; e < nx * nx; e += D::kNT) {
             const int i = e / nx, j = e - i * nx;
             if (i >= j) S.Pr[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
-        }
-        for (int e = lane; e < nu * nx; e += D::kNT) {
-            const int i = e / nx, c = e - i * nx;
-            S.Kg[t * nu * nx + e] = -S.E[c * nu + i];
-        }
-        for (int e = lane; e < nu * nu; e += D::kNT) {
-            const int i = e / nu, j = e - i * nu;
-            if (i < j) continue;
-            double a = 0;
-            for (int l = i; l < nu; l++) a += S.E[(nx + l) * nu + i] * S.E[(nx + l) * nu + j] * S.mv[l];
-            S.Minv[t * nus + sym(i, j)] = a;
         }
         __syncthreads();
     }
@@ -439,29 +429,28 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Same factorisation for the compile-time shapes, with the stage matrix in registers: lane c < nz
-// owns column c of M, lanes nz .. nz+nu-1 own the columns of the carried identity block.  A pivot
-// step broadcasts the pivot column with v_readlane (wave-uniform SGPR values) and every lane
-// updates its own column: no LDS traffic and no barrier inside the elimination.  Per stage there
-// are two barriers: after the Gram / P[A B] phase and after the results are written back.
+// Same factorisation for the compile-time shapes, with the stage matrix in registers of wave 0:
+// lane c < nz owns column c of M.  A pivot step broadcasts the pivot column with v_readlane
+// (wave-uniform SGPR values) and every lane updates its own column: no LDS traffic and no barrier
+// inside the elimination.  Two barriers per stage: after the Gram / P[A B] phase (all waves) and
+// after the write-back.
 // ---------------------------------------------------------------------------------------------
 template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
-    FSTAMP_DECL;
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
+    constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
     const int T = p.T;
-    constexpr int NXS = NX * (NX + 1) / 2, NUS = NU * (NU + 1) / 2;
+    FSTAMP_DECL;
     if (lane == 0) S.flag[0] = 0;
     for (int e = lane; e < NX * NX; e += D::kNT) {
         const int i = e / NX, j = e - i * NX;
         if (i >= j) S.Pr[T * NXS + sym(i, j)] = S.PT[e];
     }
     __syncthreads();
-    int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *Pn = S.Pr + (t + 1) * NXS;
         const ldsi *fx = S.fix + t * NUB;
-        // phase 1 (LDS): M = P + C' D C by Gram lists ; PA = Pn [A B]
+        // phase 1 (LDS, all waves): M = P + C' D C by Gram lists ; PA = Pn [A B]
         for (int e = lane; e < NE; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             const double a = S.P[i * NZ + j] + gram_entry<D>(p, S, t, e, i, j);
@@ -477,113 +466,98 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         }
         __syncthreads();
         FSTAMP(0);
-        // phase 2 (registers, wave 0 only): assemble the column, prescribe, eliminate
-        if (lane < WAVE) {
-        double col[NZ];
-        if (lane < NZ) {
+        if (lane < WAVE) { // phase 2 (registers, wave 0): assemble the column, prescribe, eliminate
+            ldsd *Lm = S.Lm + t * LMS;
+            double col[NZ];
+            if (lane < NZ) {
 #pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                double a = S.Mm[i * NZ + lane];
+                for (int i = 0; i < NZ; i++) {
+                    double a = S.Mm[i * NZ + lane];
 #pragma unroll
-                for (int l = 0; l < NX; l++) a += S.AB[l * NZ + i] * S.PA[l * NZ + lane];
-                col[i] = a;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NZ; i++) col[i] = (i - NX == lane - NZ) ? 1.0 : 0.0;
-        }
-        FSTAMP(1);
-        int nfixed = 0;
-#pragma unroll
-        for (int b = 0; b < NUB; b++) nfixed += fx[b] >= 0;
-        if (nfixed) {
-            // columns of binaries fixed to one (for the constant direction), before prescribing
-            double mbv[NZ];
-#pragma unroll
-            for (int i = 0; i < NZ; i++) mbv[i] = 0.0;
-#pragma unroll
-            for (int b = 0; b < NUB; b++)
-                if (fx[b] == 1) {
-#pragma unroll
-                    for (int i = 0; i < NZ; i++) mbv[i] += bcast(col[i], NX + NUC + b);
+                    for (int l = 0; l < NX; l++) a += S.AB[l * NZ + i] * S.PA[l * NZ + lane];
+                    col[i] = a;
                 }
-            if (lane == 0) {
+            } else {
 #pragma unroll
-                for (int i = 0; i < NZ; i++) S.g[t * NZ + i] = mbv[i];
+                for (int i = 0; i < NZ; i++) col[i] = 0.0;
             }
+            FSTAMP(1);
+            int nfixed = 0;
 #pragma unroll
-            for (int b = 0; b < NUB; b++)
-                if (fx[b] >= 0) {
-                    constexpr int dummy = 0; (void)dummy;
-                    const int cb = NX + NUC + b;
-                    if (lane < NZ) {
+            for (int b = 0; b < NUB; b++) nfixed += fx[b] >= 0;
+            if (nfixed) {
+                // columns of binaries fixed to one (for the constant direction), before prescribing
+                double mbv[NZ];
+#pragma unroll
+                for (int i = 0; i < NZ; i++) mbv[i] = 0.0;
+#pragma unroll
+                for (int b = 0; b < NUB; b++)
+                    if (fx[b] == 1) {
+#pragma unroll
+                        for (int i = 0; i < NZ; i++) mbv[i] += bcast(col[i], NX + NUC + b);
+                    }
+                if (lane == 0) {
+#pragma unroll
+                    for (int i = 0; i < NZ; i++) S.g[t * NZ + i] = mbv[i];
+                }
+#pragma unroll
+                for (int b = 0; b < NUB; b++)
+                    if (fx[b] >= 0) {
+                        const int cb = NX + NUC + b;
 #pragma unroll
                         for (int i = 0; i < NZ; i++)
                             col[i] = (lane == cb) ? (i == cb ? 1.0 : 0.0) : (i == cb ? 0.0 : col[i]);
                     }
-                }
-        } else if (lane < NZ) {
-            S.g[t * NZ + lane] = 0.0;
-        }
-        FSTAMP(2);
-        double dinv[NU];
+            } else if (lane < NZ) {
+                S.g[t * NZ + lane] = 0.0;
+            }
+            FSTAMP(2);
+            int bad = 0;
+            // The multiplier of row i at pivot j is M(i, pj) / d; by symmetry lane i holds it as
+            // col[pj] / d, so every lane keeps the multipliers of its own row and stores them once.
+            double myrow[NU], dinv[NU];
 #pragma unroll
-        for (int j = 0; j < NU; j++) {
-            if (j >= NUC && fx[j - NUC] >= 0) { // decoupled unit pivot
+            for (int j = 0; j < NU; j++) {
+                myrow[j] = 0.0;
                 dinv[j] = 1.0;
-                continue;
-            }
-            constexpr int dummy = 0; (void)dummy;
-            const int pj = NX + j;
-            const double d = bcast(col[pj], pj);
-            if (!(d > 0.0)) bad = 1;
-            double rinv = __builtin_amdgcn_rcp(d);
-            rinv = rinv * (2.0 - d * rinv);
-            dinv[j] = rinv;
-            const double cpj = col[pj];
+                if (j >= NUC && fx[j - NUC] >= 0) continue; // decoupled unit pivot: the solves skip it as well
+                const int pj = NX + j;
+                const double d = bcast(col[pj], pj);
+                if (!(d > 0.0)) bad = 1;
+                double rinv = __builtin_amdgcn_rcp(d);
+                rinv = rinv * (2.0 - d * rinv);
+                dinv[j] = rinv;
+                const double cpj = col[pj];
+                if (lane < NX || lane > pj) myrow[j] = cpj * rinv;
 #pragma unroll
-            for (int i = 0; i < NZ; i++) {
-                if (i < NX || i > pj) { // rows still to be reduced
-                    const double m = bcast(col[i], pj) * rinv;
-                    col[i] -= m * cpj;
+                for (int i = 0; i < NZ; i++) {
+                    if (i < NX || i > pj) { // rows still to be reduced
+                        const double m = bcast(col[i], pj) * rinv;
+                        col[i] -= m * cpj;
+                    }
                 }
             }
+            if (lane < NZ) {
+#pragma unroll
+                for (int j = 0; j < NU; j++) Lm[lane * NU + j] = myrow[j];
+            }
+            if (lane < NU) {
+                double dv = 1.0;
+#pragma unroll
+                for (int j = 0; j < NU; j++) dv = (lane == j) ? dinv[j] : dv;
+                S.dinv[t * NU + lane] = dv;
+            }
+            FSTAMP(3);
+            if (lane < NX) {
+#pragma unroll
+                for (int i = 0; i < NX; i++)
+                    if (i >= lane) S.Pr[t * NXS + sym(i, lane)] = col[i];
+            }
+            if (lane == 0 && bad) S.flag[0] = 1;
         }
-        FSTAMP(3);
-        // write back: Schur complement (state lanes), gain and unit-lower inverse factor (E lanes)
-        if (lane < NX) {
-#pragma unroll
-            for (int i = 0; i < NX; i++)
-                if (i >= lane) S.Pr[t * NXS + sym(i, lane)] = col[i];
-        } else if (lane >= NZ && lane < NZ + NU) {
-            const int c = lane - NZ;
-#pragma unroll
-            for (int x = 0; x < NX; x++) S.Kg[t * NU * NX + c * NX + x] = -col[x];
-#pragma unroll
-            for (int l = 0; l < NU; l++) S.E[(NX + l) * NU + c] = col[NX + l];
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int l = 0; l < NU; l++) S.mv[l] = dinv[l]; // reciprocal pivots for the inverse below
-            if (bad) S.flag[0] = 1;
-        }
-        } // wave 0
         __syncthreads();
         FSTAMP(4);
-        // phase 3: M_uu^{-1} = E_u' diag(1/pivot) E_u ; overlaps with the next stage's phase 1
-        for (int e = lane; e < NU * NU; e += D::kNT) {
-            const int i = e / NU, j = e - i * NU;
-            if (i >= j) {
-                double a = 0;
-#pragma unroll
-                for (int l = 0; l < NU; l++)
-                    if (l >= i) a += S.E[(NX + l) * NU + i] * S.E[(NX + l) * NU + j] * S.mv[l];
-                S.Minv[t * NUS + sym(i, j)] = a;
-            }
-        }
-        FSTAMP(5);
     }
-    __syncthreads();
     return S.flag[0] ? -1 : 0;
 }
 
@@ -592,16 +566,18 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
 //   rhs_d  : gs * gsrc (n entries; gsrc may be null; gsrc may alias S.g)   stage gradients
 //   x_0    : x0 if usex0 else 0                                            prescribed initial state
 //   cdyn   : cs * csrc (T*nx; csrc may be null)                            dynamics offsets
-//   useb   : fixed binaries take their value v (constant direction) or 0
+//   useb   : fixed binaries take their value v (constant direction, S.g holds the factorisation's
+//            mb on entry) or 0
 //   S.e    : D .* rhs_c on entry ; the multiplier step dz on exit
+// Generic form: every phase is spread over the threads, a barrier after each; the substitutions take
+// one barrier per pivot.
 // ---------------------------------------------------------------------------------------------
-template <class D>
-DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS>
+DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
                    const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf)
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
-    // g = rhs_d + C' e  (column lists)
-    // S.g <- (the factorisation's mb, left in S.g, if useb) - (rhs_d + C' e)
+    const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     for (int o = lane; o < T * nz; o += D::kNT) {
         const int t = o / nz, j = o - t * nz;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
@@ -611,9 +587,11 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     __syncthreads();
     // backward sweep
     for (int t = T - 1; t >= 0; t--) {
+        const ldsd *Lm = S.Lm + t * lms;
+        const ldsi *fx = S.fix + t * nub;
         const ldsd *qv = S.pv + (t + 1) * nx;
         if (csrc) {
-            const ldsd *Pn = S.Pr + (t + 1) * (nx * (nx + 1) / 2);
+            const ldsd *Pn = S.Pr + (t + 1) * nxs;
             for (int i = lane; i < nx; i += D::kNT) {
                 double a = S.pv[(t + 1) * nx + i];
                 for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * cs * csrc[t * nx + l];
@@ -626,17 +604,25 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
             double a = S.g[t * nz + j];
             for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * qv[l];
             if (j >= nx + nuc) {
-                const int f = S.fix[t * nub + (j - nx - nuc)];
+                const int f = fx[j - nx - nuc];
                 if (f >= 0) a = (useb && f == 1) ? -1.0 : 0.0;
             }
             S.mv[j] = a;
-            if (j >= nx) S.mus[t * nu + (j - nx)] = a;
         }
         __syncthreads();
-        for (int i = lane; i < nx; i += D::kNT) {
-            double a = S.mv[i];
-            for (int l = 0; l < nu; l++) a -= S.Kg[t * nu * nx + l * nx + i] * S.mv[nx + l];
-            S.pv[t * nx + i] = a;
+        // forward substitution = the row operations of the factorisation applied to the vector
+        for (int j = 0; j < nu; j++) {
+            if (j >= nuc && fx[j - nuc] >= 0) continue;
+            const double yj = S.mv[nx + j];
+            for (int i = lane; i < nz; i += D::kNT) {
+                if (i < nx) S.mv[i] -= Lm[LM_X(nx, nu, i, j)] * yj;
+                else if (i > nx + j) S.mv[i] -= Lm[LM_U(nx, nu, i - nx, j)] * yj;
+            }
+            __syncthreads();
+        }
+        for (int i = lane; i < nz; i += D::kNT) {
+            if (i < nx) S.pv[t * nx + i] = S.mv[i];
+            else S.mus[t * nu + (i - nx)] = S.mv[i];
         }
         __syncthreads();
     }
@@ -644,13 +630,27 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
     for (int i = lane; i < nx; i += D::kNT) dw[i] = usex0 ? S.x0[i] : 0.0;
     __syncthreads();
     for (int t = 0; t < T; t++) {
+        const ldsd *Lm = S.Lm + t * lms;
+        const ldsi *fx = S.fix + t * nub;
         const ldsd *x = dw + t * nz;
-        for (int i = lane; i < nu; i += D::kNT) {
-            double a = 0;
-            for (int l = 0; l < nx; l++) a += S.Kg[t * nu * nx + i * nx + l] * x[l];
-            for (int l = 0; l < nu; l++) a += S.Minv[t * (nu * (nu + 1) / 2) + sym(i, l)] * S.mus[t * nu + l];
-            dw[t * nz + nx + i] = -a;
+        // c = L_x' x + dinv .* y ; then back substitution with L_u', u = -(result)
+        for (int j = lane; j < nu; j += D::kNT) {
+            double a = S.dinv[t * nu + j] * S.mus[t * nu + j];
+            const bool fixed = j >= nuc && fx[j - nuc] >= 0;
+            if (!fixed)
+                for (int l = 0; l < nx; l++) a += Lm[LM_X(nx, nu, l, j)] * x[l];
+            S.mv[j] = a;
         }
+        __syncthreads();
+        for (int j = nu - 1; j >= 1; j--) {
+            const double uj = S.mv[j];
+            for (int i = lane; i < j; i += D::kNT) {
+                const bool fixed = i >= nuc && fx[i - nuc] >= 0;
+                if (!fixed) S.mv[i] -= Lm[LM_U(nx, nu, j, i)] * uj;
+            }
+            __syncthreads();
+        }
+        for (int i = lane; i < nu; i += D::kNT) dw[t * nz + nx + i] = -S.mv[i];
         __syncthreads();
         for (int i = lane; i < nx; i += D::kNT) {
             double a = csrc ? cs * csrc[t * nx + i] : 0.0;
@@ -659,20 +659,23 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
         }
         __syncthreads();
     }
-    // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
+    // equality multipliers lam_t = -(P_t x_t + p_t) ; dz = D (C dw) - e
     for (int o = lane; o < (T + 1) * nx; o += D::kNT) {
         const int t = o / nx, i = o - t * nx;
         double a = S.pv[o];
-        for (int l = 0; l < nx; l++) a += S.Pr[t * (nx * (nx + 1) / 2) + sym(i, l)] * dw[t * nz + l];
+        for (int l = 0; l < nx; l++) a += S.Pr[t * nxs + sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
-    for (int r = lane; r < p.M; r += D::kNT) {
-        const double d = S.D[r];
-        if (d != 0.0) { // inactive rows keep e = 0
-            int t, lr;
-            row_decode(p, r, t, lr);
-            S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * nz) - S.e[r];
-        }
+    {
+        const int M = p.M, nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+        ROWS_BEGIN(k, r)
+            const double d = R.D(k, r);
+            if (d != 0.0) { // inactive rows keep e = 0
+                int t, lr;
+                row_decode(p, r, t, lr);
+                S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * nz) - S.e[r];
+            }
+        ROWS_END
     }
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
@@ -693,17 +696,18 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, d
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same solve for the compile-time shapes, with the two recursions in registers: lane j holds
-// component j of the stage vector, the handful of values every lane needs (cost-to-go gradient,
-// inputs, state) travel by v_readlane, and everything that does not depend on the recursion
-// (C' e, M_uu^{-1} m_u, gains) is prepared in parallel phases before the sweep.  No barrier and no
-// LDS round trip on the critical path of a stage.
+// The same solve for the compile-time shapes, with the two recursions in registers of wave 0: lane j
+// holds component j of the stage vector; a substitution step broadcasts one value with v_readlane and
+// every lane updates its own component with its own multiplier (its row of L for the forward, its
+// column of L_u for the back substitution).  Everything that does not depend on the recursion (C' e)
+// is prepared by all waves before the sweep.  No barrier and no LDS round trip on the critical path.
 // ---------------------------------------------------------------------------------------------
-template <class D>
-DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS>
+DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
                        const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
+    constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
     const int T = p.T;
     FSTAMP_DECL;
     // S.g <- (mb if useb) - (rhs_d + C' e): the part of the stage gradient the recursion does not touch
@@ -724,84 +728,101 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
 #pragma unroll
         for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
         for (int t = T - 1; t >= 0; t--) {
+            const ldsd *Lm = S.Lm + t * LMS;
+            const ldsi *fx = S.fix + t * NUB;
             const double mpre = lane < NZ ? S.g[t * NZ + lane] : 0.0;
             int f = -1;
-            if (lane >= NX + NUC && lane < NZ) f = S.fix[t * NUB + lane - NX - NUC];
-            double kg[NU];
+            if (lane >= NX + NUC && lane < NZ) f = fx[lane - NX - NUC];
+            // this lane's row of the multiplier matrix (zero on and above the diagonal of L_u)
+            double mrow[NU];
+            {
+                const ldsd *row = Lm + (lane < NZ ? lane : 0) * NU; // zeros on and above the diagonal of L_u
 #pragma unroll
-            for (int l = 0; l < NU; l++) kg[l] = lane < NX ? S.Kg[t * NU * NX + l * NX + lane] : 0.0;
+                for (int j = 0; j < NU; j++) mrow[j] = row[j];
+            }
             double qv = pvr;
             if (csrc && lane < NX) {
 #pragma unroll
-                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * (NX * (NX + 1) / 2) + sym(lane, l)] * cs * csrc[t * NX + l];
+                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * NXS + sym(lane, l)] * cs * csrc[t * NX + l];
             }
-            double m = mpre;
+            double v = mpre;
 #pragma unroll
-            for (int l = 0; l < NX; l++) m += ABcol[l] * bcast(qv, l);
-            if (f >= 0) m = (useb && f == 1) ? -1.0 : 0.0;
-            if (lane >= NX && lane < NZ) S.mus[t * NU + lane - NX] = m;
-            double pn = m;
+            for (int l = 0; l < NX; l++) v += ABcol[l] * bcast(qv, l);
+            if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
+            // forward substitution: the factorisation's row operations applied to the vector
 #pragma unroll
-            for (int l = 0; l < NU; l++) pn -= kg[l] * bcast(m, NX + l);
-            pvr = pn;
-            if (lane < NX) S.pv[t * NX + lane] = pn;
+            for (int j = 0; j < NU; j++) {
+                if (j >= NUC && fx[j - NUC] >= 0) continue;
+                v -= mrow[j] * bcast(v, NX + j);
+            }
+            if (lane >= NX && lane < NZ) S.mus[t * NU + lane - NX] = v; // y = L_u^{-1} m_u
+            pvr = v;                                                     // lanes < NX: p_t
+            if (lane < NX) S.pv[t * NX + lane] = v;
         }
     }
     __syncthreads();
     FSTAMP(7);
-    // M_uu^{-1} m_u for every stage at once
-    for (int o = lane; o < T * NU; o += D::kNT) {
-        const int t = o / NU, i = o - t * NU;
-        double a = 0;
-#pragma unroll
-        for (int l = 0; l < NU; l++) a += S.Minv[t * (NU * (NU + 1) / 2) + sym(i, l)] * S.mus[t * NU + l];
-        S.g[o] = a; // the stage gradients are consumed: their storage takes M_uu^{-1} m_u
-    }
-    __syncthreads();
-    FSTAMP(8);
     if (lane < WAVE) { // forward sweep (wave 0)
         double ABrow[NZ];
 #pragma unroll
         for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
         double xr = (lane < NX && usex0) ? S.x0[lane] : 0.0;
         for (int t = 0; t < T; t++) {
-            double kgr[NX];
+            const ldsd *Lm = S.Lm + t * LMS;
+            const ldsi *fx = S.fix + t * NUB;
+            const bool mine_fixed = lane >= NUC && lane < NU && fx[lane - NUC] >= 0;
+            // lane j < NU: column j of L_x and of L_u (entries below the diagonal)
+            double lx[NX], lcol[NU];
+            {
+                const ldsd *colp = Lm + (lane < NU ? lane : 0); // column `lane` of the block, stride NU
+                const bool on = lane < NU && !mine_fixed;         // a skipped pivot's column is stale
 #pragma unroll
-            for (int l = 0; l < NX; l++) kgr[l] = lane < NU ? S.Kg[t * NU * NX + lane * NX + l] : 0.0;
-            const double ru = lane < NU ? S.g[t * NU + lane] : 0.0;
+                for (int l = 0; l < NX; l++) lx[l] = on ? colp[l * NU] : 0.0;
+#pragma unroll
+                for (int i = 0; i < NU; i++) lcol[i] = on ? colp[(NX + i) * NU] : 0.0;
+            }
+            double cur = lane < NU ? S.dinv[t * NU + lane] * S.mus[t * NU + lane] : 0.0;
             const double cdy = (csrc && lane < NX) ? cs * csrc[t * NX + lane] : 0.0;
-            double u = -ru, xn = cdy;
+            double xn = cdy;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
                 const double xl = bcast(xr, l);
-                u -= kgr[l] * xl;
+                cur += lx[l] * xl;
                 xn += ABrow[l] * xl;
             }
+            // back substitution with L_u' ; u_j = -(value of lane j once its turn has come)
 #pragma unroll
-            for (int l = 0; l < NU; l++) xn += ABrow[NX + l] * bcast(u, l);
+            for (int j = NU - 1; j >= 0; j--) {
+                const double uj = bcast(cur, j);
+                cur -= lcol[j] * uj; // only lanes i < j hold a nonzero (j, i) entry
+                xn -= ABrow[NX + j] * uj;
+            }
             if (lane < NX) dw[t * NZ + lane] = xr;
-            if (lane < NU) dw[t * NZ + NX + lane] = u;
+            if (lane < NU) dw[t * NZ + NX + lane] = -cur;
             xr = xn;
         }
         if (lane < NX) dw[T * NZ + lane] = xr;
     }
     __syncthreads();
     FSTAMP(9);
-    // equality multipliers lam_t = -(Pr_t x_t + p_t) ; dz = D (C dw) - e
+    // equality multipliers lam_t = -(P_t x_t + p_t) ; dz = D (C dw) - e
     for (int o = lane; o < (T + 1) * NX; o += D::kNT) {
         const int t = o / NX, i = o - t * NX;
         double a = S.pv[o];
 #pragma unroll
-        for (int l = 0; l < NX; l++) a += S.Pr[t * (NX * (NX + 1) / 2) + sym(i, l)] * dw[t * NZ + l];
+        for (int l = 0; l < NX; l++) a += S.Pr[t * NXS + sym(i, l)] * dw[t * NZ + l];
         dlam[o] = -a;
     }
-    for (int r = lane; r < p.M; r += D::kNT) {
-        const double d = S.D[r];
-        if (d != 0.0) { // inactive rows keep e = 0
-            int t, lr;
-            row_decode(p, r, t, lr);
-            S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * NZ) - S.e[r];
-        }
+    {
+        const int M = p.M, nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+        ROWS_BEGIN(k, r)
+            const double d = R.D(k, r);
+            if (d != 0.0) { // inactive rows keep e = 0
+                int t, lr;
+                row_decode(p, r, t, lr);
+                S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * NZ) - S.e[r];
+            }
+        ROWS_END
     }
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
@@ -824,12 +845,12 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, int lane, const ldsd *gsr
     FSTAMP(10);
 }
 
-template <class D>
-DEV void kkt_dispatch(const DevProb &p, const Lds &S, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS>
+DEV void kkt_dispatch(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
                       const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
-    if constexpr (D::kNX > 0) kkt_solve_reg<D>(p, S, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
-    else kkt_solve<D>(p, S, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
+    if constexpr (D::kNX > 0) kkt_solve_reg<D, RS>(p, S, R, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
+    else kkt_solve<D, RS>(p, S, R, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
 }
 
 // f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
@@ -890,7 +911,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         const bool on = row_active<D>(p, S.fix, t, lr, term_on);
         mact += on;
         R.s(k, r) = 1.0;
-        S.z[r] = on ? 1.0 : 0.0;
+        R.z(k, r) = on ? 1.0 : 0.0;
     ROWS_END
     mact = (int)block_sum<D>((double)mact, S.red, lane);
     for (int i = lane; i < n; i += D::kNT) S.w[i] = 0.0;
@@ -913,6 +934,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
     for (it = 0; it <= p.max_iter; it++) {
         STAMP(7);
         // ---------------- residuals ----------------
+        ROWS_BEGIN(k, r)
+            S.e[r] = R.z(k, r); // S.e <- z for the C'z products below
+        ROWS_END
+        __syncthreads();
         double wPw = 0;
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
@@ -933,7 +958,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 if (j < nx) a += S.lam[t * nx + j];
                 for (int l = 0; l < nx; l++) a -= S.AB[l * nz + j] * S.lam[(t + 1) * nx + l];
                 if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
-                a += ccol_dot<D>(p, S, t, j, S.z);
+                a += ccol_dot<D>(p, S, t, j, S.e);
             }
             double pw = 0; // (P w)_o
             {
@@ -961,13 +986,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             row_decode(p, r, t, lr);
             double a = 0;
             if (row_active<D>(p, S.fix, t, lr, term_on)) {
-                const double zr = S.z[r], sr = R.s(k, r), hh = hrow(p, S, lr);
+                const double zr = R.z(k, r), sr = R.s(k, r), hh = hrow(p, S, lr);
                 a = sr - hh * tau + crow_dot<D>(p, S, lr, S.w + t * nz);
                 hz += hh * zr;
                 sz += sr * zr;
                 zinf = fmax(zinf, zr);
             }
-            R.rc(k, r) = a;
             rcinf = fmax(rcinf, fabs(a));
         ROWS_END
         for (int o = lane; o < (T + 1) * nx; o += D::kNT) yinf = fmax(yinf, fabs(S.lam[o]));
@@ -993,33 +1017,42 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             double *tr = trace + it * 8;
             tr[0] = tau; tr[1] = kap; tr[2] = mu; tr[3] = rcinf / tau; tr[4] = rdinf / tau; tr[5] = gap; tr[6] = eta; tr[7] = certinf;
         }
-        // once the test has been met, the extra iteration is accepted at 100 x tol: it sits at the
-        // precision floor of the linear algebra and must not be asked to pass 1e-8 again
-        const double tl = extra_done ? 100.0 * p.tol : p.tol;
-        if (rcinf / tau <= tl * (1 + winf / tau + x0inf) && rdinf / tau <= tl * (1 + zinf / tau) &&
-            gap <= tl * (1 + fmin(fabs(pobj), fabs(dob)))) {
-            // the test is met: one more iteration (convergence is superlinear here, so the CPU
-            // oracle and this kernel agree even if they cross the threshold an iteration apart),
-            // unless the iterate is already far beyond the tolerance (mu < 1e-11)
-            status = HMPC_OPTIMAL;
-            if (extra_done >= 1 || it == p.max_iter || mu < 1e-11) break;
-            extra_done++;
-        } else if (status == HMPC_OPTIMAL) {
-            // the extra step made things worse (precision floor): undo it -- the direction is still
-            // in place -- and return the iterate that met the test
-            for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
-            for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
-            for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
-            ROWS_BEGIN(k, r)
-                if (S.D[r] != 0.0) {
-                    S.z[r] -= last_alpha * R.dz(k, r);
-                    R.s(k, r) -= last_alpha * R.prod(k, r);
-                }
-            ROWS_END
-            tau -= last_alpha * last_dtau;
-            kap -= last_alpha * last_dkap;
-            __syncthreads();
-            break;
+        // Two levels (as in Ipopt's acceptable / desired tolerances).  ACCEPTABLE: scaled residuals and
+        // gap <= tol.  DESIRED: acceptable and gap, dual residual <= 1e-2 tol -- they bound the suboptimality, and
+        // with the curvature of this cost a 1e-8 gap still leaves ~2e-5 in the trajectory; this kernel
+        // and the CPU oracle may stop an iteration apart and must still agree to 1e-5.  Once an
+        // acceptable iterate exists, up to 3 more iterations are spent on the desired level; if one of
+        // them is worse (precision floor of the linear algebra) it is undone -- the direction is still
+        // in place -- and the acceptable iterate returned.
+        {
+            const double gtol = p.tol * (1 + fmin(fabs(pobj), fabs(dob)));
+            const bool acceptable = rcinf / tau <= p.tol * (1 + winf / tau + x0inf) &&
+                                    rdinf / tau <= p.tol * (1 + zinf / tau) && gap <= gtol;
+            if (acceptable) {
+                status = HMPC_OPTIMAL;
+                if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * p.tol * (1 + zinf / tau)) || extra_done >= 3 || it == p.max_iter) break;
+                extra_done++;
+            } else if (status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
+                       rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol) {
+                // the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex
+                // code's default): nothing more can be gained on an interior-free node
+                status = HMPC_OPTIMAL;
+                break;
+            } else if (status == HMPC_OPTIMAL) {
+                for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
+                for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
+                for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
+                ROWS_BEGIN(k, r)
+                    if (R.D(k, r) != 0.0) {
+                        R.z(k, r) -= last_alpha * R.dz(k, r);
+                        R.s(k, r) -= last_alpha * R.prod(k, r);
+                    }
+                ROWS_END
+                tau -= last_alpha * last_dtau;
+                kap -= last_alpha * last_dkap;
+                __syncthreads();
+                break;
+            }
         }
         // third clause: tau has vanished (ten orders below kappa) -- infeasible by less than a certificate
         // can resolve in double precision; reported with the multipliers at hand
@@ -1030,13 +1063,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         if (it == p.max_iter) break;
 
         // ---------------- factorisation ----------------
+        __syncthreads(); // every thread is done reading z from S.e
         ROWS_BEGIN(k, r)
-            const double zr = S.z[r]; // zero on inactive rows
+            const double zr = R.z(k, r); // zero on inactive rows
             const double d = zr != 0.0 ? zr / R.s(k, r) : 0.0;
-            int t, lr;
-            row_decode(p, r, t, lr);
-            S.D[r] = d;
-            S.e[r] = d * hrow(p, S, lr); // right-hand side of the constant direction
+            R.D(k, r) = d;
+            S.e[r] = d; // S.e <- D for the Gram phase of the factorisation
         ROWS_END
         __syncthreads();
         STAMP(1);
@@ -1045,15 +1077,18 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         else frc = factor<D>(p, S, lane);
         if (frc != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
         STAMP(2);
+        ROWS_BEGIN(k, r)
+            int t, lr;
+            row_decode(p, r, t, lr);
+            S.e[r] = R.D(k, r) * hrow(p, S, lr); // right-hand side of the constant direction
+        ROWS_END
+        __syncthreads();
 
         // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-        kkt_dispatch<D>(p, S, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+        kkt_dispatch<D, RS>(p, S, R, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
         STAMP(3);
         double g1 = 0;
         g1 = wPv<D>(p, S, lane, S.w1);
-        ROWS_BEGIN(k, r)
-            R.z1(k, r) = S.e[r];
-        ROWS_END
         double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
         {
             double v[2] = {g1, fyhz1};
@@ -1070,17 +1105,20 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             __syncthreads();
             ROWS_BEGIN(k, r)
                 double v = 0;
-                const double d = S.D[r];
+                const double d = R.D(k, r);
                 if (d != 0.0) { // active row
-                    const double zr = S.z[r];
-                    const double dsr = R.s(k, r) * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
-                    v = d * (-lin * R.rc(k, r) + dsr / zr);
+                    int t, lr;
+                    row_decode(p, r, t, lr);
+                    const double zr = R.z(k, r), sr = R.s(k, r);
+                    const double rc = sr - hrow(p, S, lr) * tau + crow_dot<D>(p, S, lr, S.w + t * nz); // row residual
+                    const double dsr = sr * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
+                    v = d * (-lin * rc + dsr / zr);
                 }
                 S.e[r] = v;
             ROWS_END
             __syncthreads();
             STAMP(4);
-            kkt_dispatch<D>(p, S, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
+            kkt_dispatch<D, RS>(p, S, R, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
             STAMP(3);
             double g2 = 0;
             g2 = wPv<D>(p, S, lane, S.w2);
@@ -1098,12 +1136,31 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += dtau * S.lam1[o];
             for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += dtau * S.nuf1[o];
             ROWS_BEGIN(k, r)
-                const double v = S.D[r] != 0.0 ? S.e[r] + dtau * R.z1(k, r) : 0.0;
+                double v = 0.0;
+                const double d = R.D(k, r);
+                if (d != 0.0) {
+                    int t, lr;
+                    row_decode(p, r, t, lr);
+                    // multiplier step of the constant direction: D (C w1 - h)
+                    const double z1 = d * (crow_dot<D>(p, S, lr, S.w1 + t * nz) - hrow(p, S, lr));
+                    v = S.e[r] + dtau * z1;
+                }
                 S.e[r] = v;
                 R.dz(k, r) = v;
             ROWS_END
             __syncthreads();
-            if (pass == 1 && p.refine && mu < 1e-3) { // pays only once D = z/s spans many orders of magnitude
+            // Iterative refinement against the three linear blocks of the Newton system at this dtau:
+            // one step once mu < 1e-3, two once mu < 1e-7 (one step squares the relative error of a
+            // solve; the stage cost's small curvature needs the dual residual well below the stopping
+            // tolerance for the trajectory to be accurate to 1e-5).
+            const int nref = (pass == 1 && p.refine) ? (mu < 1e-7 ? 2 : mu < 1e-3 ? 1 : 0) : 0;
+            for (int rf = 0; rf < nref; rf++) {
+                if (rf > 0) { // S.e <- current dz for the C' dz products (the previous round left its correction there)
+                    ROWS_BEGIN(k, r)
+                        S.e[r] = R.dz(k, r);
+                    ROWS_END
+                    __syncthreads();
+                }
                 // residual of the three linear blocks at the combined direction (x_0 and fixed
                 // binaries are met by construction), then one correction solve
                 for (int o = lane; o < n; o += D::kNT) {
@@ -1127,18 +1184,19 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     const int t = o / nx, i = o - t * nx;
                     double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
                     for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * S.w2[t * nz + l];
-                    S.rdyn[o] = a; // in place: the dynamics residual is recomputed next iteration
+                    S.edyn[o] = a;
                 }
                 __syncthreads();
                 ROWS_BEGIN(k, r)
                     double v = 0;
-                    const double d = S.D[r];
+                    const double d = R.D(k, r);
                     if (d != 0.0) {
                         int t, lr;
                         row_decode(p, r, t, lr);
-                        const double zr = S.z[r], sr = R.s(k, r);
+                        const double zr = R.z(k, r), sr = R.s(k, r);
+                        const double rc = sr - hrow(p, S, lr) * tau + crow_dot<D>(p, S, lr, S.w + t * nz);
                         const double dsr = sr * zr + R.prod(k, r) - sigma * mu;
-                        const double a = -lin * R.rc(k, r) + dsr / zr + dtau * hrow(p, S, lr) + S.e[r] * sr / zr -
+                        const double a = -lin * rc + dsr / zr + dtau * hrow(p, S, lr) + S.e[r] * sr / zr -
                                          crow_dot<D>(p, S, lr, S.w2 + t * nz);
                         v = d * a;
                     }
@@ -1146,13 +1204,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 ROWS_END
                 __syncthreads();
                 STAMP(5);
-                kkt_dispatch<D>(p, S, lane, S.g, 1.0, false, S.rdyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+                kkt_dispatch<D, RS>(p, S, R, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
                 STAMP(3);
                 for (int o = lane; o < n; o += D::kNT) S.w2[o] += S.w1[o];
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += S.lam1[o];
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += S.nuf1[o];
                 ROWS_BEGIN(k, r)
-                    if (S.D[r] != 0.0) R.dz(k, r) += S.e[r];
+                    if (R.D(k, r) != 0.0) R.dz(k, r) += S.e[r];
                 ROWS_END
             }
             // slack step from the complementarity row ; step to the boundary
@@ -1160,8 +1218,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             if (dtau < 0) amax = fmin(amax, -tau / dtau);
             if (dkap < 0) amax = fmin(amax, -kap / dkap);
             ROWS_BEGIN(k, r)
-                if (S.D[r] != 0.0) {
-                    const double dz = R.dz(k, r), sr = R.s(k, r), zr = S.z[r];
+                if (R.D(k, r) != 0.0) {
+                    const double dz = R.dz(k, r), sr = R.s(k, r), zr = R.z(k, r);
                     const double dsr = sr * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
                     const double ds = -(dsr + sr * dz) / zr;
                     if (dz < 0) amax = fmin(amax, -zr / dz);
@@ -1183,8 +1241,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] += alpha * S.lam2[o];
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] += alpha * S.nuf2[o];
                 ROWS_BEGIN(k, r)
-                    if (S.D[r] != 0.0) {
-                        S.z[r] += alpha * R.dz(k, r);
+                    if (R.D(k, r) != 0.0) {
+                        R.z(k, r) += alpha * R.dz(k, r);
                         R.s(k, r) += alpha * R.prod(k, r);
                     }
                 ROWS_END
@@ -1221,7 +1279,7 @@ template <class D> DEV double terminal_violation(const DevProb &p, const Lds &S,
     return block_max<D>(tv, S.red, lane);
 }
 
-// Output record in the reference's conventions (subproblem_solution.py:68-168).
+// Output record in the reference's conventions (subproblem_solution.py:68-168).  S.e holds z here.
 template <class D>
 DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, double tau, int qp, const DevOut &out)
 {
@@ -1231,7 +1289,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     double scale;
     if (inf) {
         double big = 0;
-        for (int r = lane; r < M; r += D::kNT) big = fmax(big, S.z[r]);
+        for (int r = lane; r < M; r += D::kNT) big = fmax(big, S.e[r]);
         for (int o = lane; o < (T + 1) * nx; o += D::kNT) big = fmax(big, fabs(S.lam[o]));
         for (int o = lane; o < T * nub; o += D::kNT) big = fmax(big, fabs(S.nuf[o]));
         scale = 1.0 / block_max<D>(big, S.red, lane); // Farkas ray: scale is arbitrary
@@ -1253,7 +1311,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
         row_decode(p, r, t, lr);
         if (lr < p.nc || lr >= p.mreg) { // [F G] rows and terminal-set rows are the reference's mu_t
             const double sc = lr < p.nc ? p.reg.scale[lr] : p.sct[lr - p.mreg];
-            const double v = S.z[r] * scale * sc;
+            const double v = S.e[r] * scale * sc;
             if (dual) dual[o_mu + t * p.nc + (lr < p.nc ? lr : p.nc + (lr - p.mreg))] = v;
             farkas -= (hrow(p, S, lr) / sc) * v;
         }
@@ -1262,8 +1320,8 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
         const int t = o / nub, b = o - t * nub;
         double lo, hi;
         if (S.fix[o] < 0) {
-            lo = S.z[t * p.mreg + p.nc + b] * scale;
-            hi = S.z[t * p.mreg + p.nc + nub + b] * scale;
+            lo = S.e[t * p.mreg + p.nc + b] * scale;
+            hi = S.e[t * p.mreg + p.nc + nub + b] * scale;
             farkas -= hi;
         } else {
             const double v = S.nuf[o] * scale;
@@ -1326,17 +1384,17 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsd *q = (ldsd *)smem;
         auto take = [&](int cnt) { ldsd *r = q; q += cnt; return r; };
         S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
-        S.z = take(M); S.D = take(M); S.e = take(M);
-        const int nus = nu * (nu + 1) / 2, nxs = nx * (nx + 1) / 2;
-        S.Minv = take(T * nus); S.Kg = take(T * nu * nx); S.Pr = take((T + 1) * nxs);
+        S.e = take(M);
+        const int nxs = nx * (nx + 1) / 2;
+        S.Lm = take(T * LM_STAGE(nx, nu)); S.dinv = take(T * nu); S.Pr = take((T + 1) * nxs);
         S.mus = take(T * nu);
-        S.rd = take(n); S.rdyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
+        S.rd = take(n); S.rdyn = take(T * nx); S.edyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         // the second direction is dead while a factorisation runs: its storage doubles as the
         // factorisation scratch (stage matrix, carried identity block, Pn [A B])
-        const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + nz * nu + nx * nz;
+        const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
         S.w2 = take(dir2 > fscr ? dir2 : fscr); S.lam2 = S.w2 + n; S.nuf2 = S.lam2 + (T + 1) * nx;
-        S.Mm = S.w2; S.E = S.Mm + nz * nz; S.PA = S.E + nz * nu;
+        S.Mm = S.w2; S.PA = S.Mm + nz * nz;
         S.q = take(nx); S.mv = take(nz); S.red = take(40);
         S.x0 = take(nx);
         S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
@@ -1390,6 +1448,13 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
                 if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
                 if (done) break;
             }
+        }
+        __syncthreads();
+        {
+            const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+            ROWS_BEGIN(k, r)
+                S.e[r] = R.z(k, r);
+            ROWS_END
         }
         __syncthreads();
         write_record<D>(p, S, lane, status, tau, qp, out);

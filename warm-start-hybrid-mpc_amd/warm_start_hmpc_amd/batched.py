@@ -253,7 +253,7 @@ class BatchedMPC(object):
         ws = [None] * K
         active = list(range(K))
         stats = dict(nodes_ws=[[] for _ in range(K)], nodes_cs=[[] for _ in range(K)], len_ws=[[] for _ in range(K)],
-                     costs=[[] for _ in range(K)], errors=[[] for _ in range(K)])
+                     costs=[[] for _ in range(K)], errors=[[] for _ in range(K)], cost_mismatches=[])
         tic = perf_counter()
         steps_done = 0
         for t in range(n_steps):
@@ -266,9 +266,10 @@ class BatchedMPC(object):
                 r = warm[j]
                 if cold is not None:
                     stats['nodes_cs'][k].append(cold[j]['solves'])
-                    assert np.isinf(r['objective']) == np.isinf(cold[j]['objective'])
-                    if np.isfinite(r['objective']):
-                        assert abs(r['objective'] - cold[j]['objective']) <= 1e-6 * (1 + abs(r['objective']))
+                    # the reference asserts np.isclose(cost_cs, cost_ws) (statistical_analysis.py:171); here a
+                    # disagreement is counted and reported instead of ending the study
+                    if not np.isclose(r['objective'], cold[j]['objective'], rtol=1e-5, atol=1e-8):
+                        stats['cost_mismatches'].append((seeds[k], t, cold[j]['objective'], r['objective']))
                 stats['nodes_ws'][k].append(r['solves'])
                 if not np.isfinite(r['objective']):
                     continue                        # infeasible: the simulation ends here

@@ -58,6 +58,8 @@ def main(argv=None):
             print('cold solves/step: mean %.2f min %d max %d' % (cs.mean(), cs.min(), cs.max()))
         lw = np.array([st['len_ws'][k] for k in full])
         print('cover size: min %d max %d' % (lw.min(), lw.max()))
+    print('warm/cold cost disagreements (np.isclose rtol 1e-5): %d of %d steps %s'
+          % (len(st['cost_mismatches']), st['steps'], st['cost_mismatches'][:3]))
     print('wall %.2f s, %.1f MPC steps/s (all simulations)' % (st['wall'], st['steps_per_sec']))
     return 0
 
