@@ -44,11 +44,11 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
     size_t d = 0, i = 0;
-    const size_t nxs = nx * (nx + 1) / 2, lms = (nx + nu) * nu;
+    const size_t nxs = nx * (nx + 1) / 2, lms = nx * nu + nu * (nu - 1) / 2;
     const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
     d += dir;                                                             // w lam nuf
     d += M;                                                               // e (row vector: z / D / D.*rhs / dz in turn)
-    d += T * lms + T * nu + (T + 1) * nxs + T * nu;                       // Lm dinv Pr mus
+    d += T * lms + T * nu + (T + 1) * nxs;                                // Lm dinv Pr
     d += n + 2 * T * nx + n + (T + 1) * nx;                               // rd rdyn edyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
     d += nx + nz + 40;                                                    // q mv red

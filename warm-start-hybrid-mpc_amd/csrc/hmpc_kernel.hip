@@ -142,7 +142,7 @@ typedef Lists<const ldsi *, const ldsd *> ListsL;
 struct Lds {
     ldsd *w, *lam, *nuf;
     ldsd *e; // the one row-indexed LDS vector: in turn z (for C'z), D (for the Gram phase), D.*rhs and dz
-    ldsd *Lm, *dinv, *Pr, *mus;   // elimination multipliers, reciprocal pivots, cost-to-go (packed), L_u^{-1} m_u
+    ldsd *Lm, *dinv, *Pr;         // elimination multipliers, reciprocal pivots, cost-to-go (packed)
     ldsd *rd, *rdyn, *edyn, *g, *pv;
     ldsd *w1, *lam1, *nuf1, *w2, *lam2, *nuf2;
     ldsd *Mm, *PA, *q, *mv;
@@ -197,10 +197,14 @@ struct Rows<0> {
     DEV double &prod(int, int r) { return prod_[r]; }
     DEV void bind(double *base, int Mpad) { s_ = base; z_ = base + Mpad; D_ = base + 2 * Mpad; dz_ = base + 3 * Mpad; prod_ = base + 4 * Mpad; }
 };
-// loop over the rows of this lane: slot k, row r
+// loop over the rows of this lane: slot k, row r.  The row index is made opaque to the optimiser in
+// every loop: otherwise everything derived from it (stage, local row, a dozen addresses per slot) is
+// hoisted out of the interior-point loop for all slots at once and spills to scratch memory.
+#define ROW_OPAQUE(r) asm volatile("" : "+v"(r))
 #define ROWS_BEGIN(k, r)                                   \
     _Pragma("unroll") for (int k = 0; k < nslot; k++) {   \
-        const int r = k * D::kNT + lane;                   \
+        int r = k * D::kNT + lane;                         \
+        ROW_OPAQUE(r);                                     \
         if (r < M) {
 #define ROWS_END }}
 
@@ -329,11 +333,11 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 // stable and break the iteration once D = z/s spans ~24 orders of magnitude (mu ~ 1e-12); this was
 // observed on the GPU and reproduced on the CPU before this form was adopted.
 // ---------------------------------------------------------------------------------------------
-// dense (nx + nu) x nu block per stage, zeros where a row is not below its pivot: a lane's row is nu
-// contiguous doubles
-#define LM_STAGE(nx, nu) (((nx) + (nu)) * (nu))
-#define LM_X(nx, nu, x, j) ((x) * (nu) + (j))          /* state row x, pivot j  */
-#define LM_U(nx, nu, i, j) (((nx) + (i)) * (nu) + (j)) /* input row i, pivot j  */
+// per stage: the multipliers of the state rows ("L_x", nx x nu, dense: a lane's row is nu contiguous
+// doubles) followed by the strictly lower triangle of L_u packed by rows (row i holds its i entries)
+#define LM_STAGE(nx, nu) ((nx) * (nu) + (nu) * ((nu) - 1) / 2)
+#define LM_X(nx, nu, x, j) ((x) * (nu) + (j))                       /* state row x, pivot j     */
+#define LM_U(nx, nu, i, j) ((nx) * (nu) + (i) * ((i) - 1) / 2 + (j)) /* input row i, pivot j < i */
 
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 {
@@ -537,9 +541,11 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                     }
                 }
             }
-            if (lane < NZ) {
+            if (lane < NZ) { // rows of the states: NU entries; row i of the inputs: its i entries (zeros at skipped pivots)
+                ldsd *row = Lm + (lane < NX ? lane * NU : LM_U(NX, NU, lane - NX, 0));
 #pragma unroll
-                for (int j = 0; j < NU; j++) Lm[lane * NU + j] = myrow[j];
+                for (int j = 0; j < NU; j++)
+                    if (lane < NX || j < lane - NX) row[j] = myrow[j];
             }
             if (lane < NU) {
                 double dv = 1.0;
@@ -622,7 +628,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const 
         }
         for (int i = lane; i < nz; i += D::kNT) {
             if (i < nx) S.pv[t * nx + i] = S.mv[i];
-            else S.mus[t * nu + (i - nx)] = S.mv[i];
+            else dw[t * nz + i] = S.mv[i]; // y = L_u^{-1} m_u, parked in the input slots until the forward sweep
         }
         __syncthreads();
     }
@@ -635,7 +641,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const 
         const ldsd *x = dw + t * nz;
         // c = L_x' x + dinv .* y ; then back substitution with L_u', u = -(result)
         for (int j = lane; j < nu; j += D::kNT) {
-            double a = S.dinv[t * nu + j] * S.mus[t * nu + j];
+            double a = S.dinv[t * nu + j] * dw[t * nz + nx + j];
             const bool fixed = j >= nuc && fx[j - nuc] >= 0;
             if (!fixed)
                 for (int l = 0; l < nx; l++) a += Lm[LM_X(nx, nu, l, j)] * x[l];
@@ -716,6 +722,17 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
         S.g[o] = (useb ? S.g[o] : 0.0) - a;
     }
+    // S.pv[t] <- P_{t+1} c_t (lanes (t, i)): the part of q_t = p_{t+1} + P_{t+1} c_t that does not depend on the
+    // recursion; stage t reads it before it stores p_t in the same place
+    for (int o = lane; o < T * NX; o += D::kNT) {
+        const int t = o / NX, i = o - t * NX;
+        double a = 0.0;
+        if (csrc) {
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += S.Pr[(t + 1) * NXS + sym(i, l)] * (cs * csrc[t * NX + l]);
+        }
+        S.pv[o] = a;
+    }
     double pvr = 0.0; // lane i < NX: p_{t+1}[i]
     if (lane < NX) {
         pvr = -(gsrc ? gs * gsrc[T * NZ + lane] : 0.0);
@@ -723,27 +740,44 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
     }
     __syncthreads();
     FSTAMP(6);
+    // Both sweeps are software pipelined: everything stage t reads from LDS does not depend on the
+    // recursion and is fetched while stage t +- 1 runs its chain of v_readlane / FMA steps, so that no
+    // LDS latency sits on the critical path.  Skipped pivots (fixed binaries) have zero multipliers:
+    // their substitution steps are no-ops and need no branch.
     if (lane < WAVE) { // backward sweep (wave 0)
         double ABcol[NX];
 #pragma unroll
         for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
+        // this lane's row of the multipliers: a state row has NU entries, input row i its i entries
+        const int rowoff = lane < NX ? lane * NU : lane < NZ ? LM_U(NX, NU, lane - NX, 0) : 0;
+        const int rowlen = lane < NX ? NU : lane < NZ ? lane - NX : 0;
+        const int gl = lane < NZ ? lane : 0, bl = (lane >= NX + NUC && lane < NZ) ? lane - NX - NUC : 0;
+        const int pl = lane < NX ? lane : 0;
+        double mrow_n[NU], mpre_n, qc_n;
+        int f_n;
+        {
+            const ldsd *row = S.Lm + (T - 1) * LMS + rowoff;
+#pragma unroll
+            for (int j = 0; j < NU; j++) mrow_n[j] = row[j];
+            mpre_n = S.g[(T - 1) * NZ + gl];
+            f_n = S.fix[(T - 1) * NUB + bl];
+            qc_n = S.pv[(T - 1) * NX + pl];
+        }
         for (int t = T - 1; t >= 0; t--) {
-            const ldsd *Lm = S.Lm + t * LMS;
-            const ldsi *fx = S.fix + t * NUB;
-            const double mpre = lane < NZ ? S.g[t * NZ + lane] : 0.0;
-            int f = -1;
-            if (lane >= NX + NUC && lane < NZ) f = fx[lane - NX - NUC];
-            // this lane's row of the multiplier matrix (zero on and above the diagonal of L_u)
             double mrow[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) mrow[j] = j < rowlen ? mrow_n[j] : 0.0;
+            const double mpre = lane < NZ ? mpre_n : 0.0;
+            const int f = (lane >= NX + NUC && lane < NZ) ? f_n : -1;
+            const double qv = pvr + qc_n;
             {
-                const ldsd *row = Lm + (lane < NZ ? lane : 0) * NU; // zeros on and above the diagonal of L_u
+                const int tn = t > 0 ? t - 1 : 0; // the last round fetches stage 0 again (unused)
+                const ldsd *row = S.Lm + tn * LMS + rowoff;
 #pragma unroll
-                for (int j = 0; j < NU; j++) mrow[j] = row[j];
-            }
-            double qv = pvr;
-            if (csrc && lane < NX) {
-#pragma unroll
-                for (int l = 0; l < NX; l++) qv += S.Pr[(t + 1) * NXS + sym(lane, l)] * cs * csrc[t * NX + l];
+                for (int j = 0; j < NU; j++) mrow_n[j] = row[j];
+                mpre_n = S.g[tn * NZ + gl];
+                f_n = S.fix[tn * NUB + bl];
+                qc_n = S.pv[tn * NX + pl];
             }
             double v = mpre;
 #pragma unroll
@@ -751,12 +785,9 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
             if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
             // forward substitution: the factorisation's row operations applied to the vector
 #pragma unroll
-            for (int j = 0; j < NU; j++) {
-                if (j >= NUC && fx[j - NUC] >= 0) continue;
-                v -= mrow[j] * bcast(v, NX + j);
-            }
-            if (lane >= NX && lane < NZ) S.mus[t * NU + lane - NX] = v; // y = L_u^{-1} m_u
-            pvr = v;                                                     // lanes < NX: p_t
+            for (int j = 0; j < NU; j++) v -= mrow[j] * bcast(v, NX + j);
+            if (lane >= NX && lane < NZ) dw[t * NZ + lane] = v; // y = L_u^{-1} m_u, parked in the input slots
+            pvr = v;                                            // lanes < NX: p_t
             if (lane < NX) S.pv[t * NX + lane] = v;
         }
     }
@@ -767,23 +798,39 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
 #pragma unroll
         for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
         double xr = (lane < NX && usex0) ? S.x0[lane] : 0.0;
+        const int cl = lane < NU ? lane : 0, pl = lane < NX ? lane : 0;
+        // lane j < NU: column j of L_x and of L_u (entries below the diagonal), reciprocal pivot, y_j
+        double lx_n[NX], lcol_n[NU], dinv_n, y_n, cdy_n;
+        {
+            const ldsd *colp = S.Lm + cl;
+#pragma unroll
+            for (int l = 0; l < NX; l++) lx_n[l] = colp[LM_X(NX, NU, l, 0)];
+#pragma unroll
+            for (int i = 1; i < NU; i++) lcol_n[i] = colp[LM_U(NX, NU, i, 0)];
+            dinv_n = S.dinv[cl];
+            y_n = dw[NX + cl];
+            cdy_n = csrc ? csrc[pl] : 0.0;
+        }
         for (int t = 0; t < T; t++) {
-            const ldsd *Lm = S.Lm + t * LMS;
-            const ldsi *fx = S.fix + t * NUB;
-            const bool mine_fixed = lane >= NUC && lane < NU && fx[lane - NUC] >= 0;
-            // lane j < NU: column j of L_x and of L_u (entries below the diagonal)
             double lx[NX], lcol[NU];
+#pragma unroll
+            for (int l = 0; l < NX; l++) lx[l] = lane < NU ? lx_n[l] : 0.0;
+            lcol[0] = 0.0;
+#pragma unroll
+            for (int i = 1; i < NU; i++) lcol[i] = lane < i ? lcol_n[i] : 0.0; // row i has entries in columns < i
+            double cur = lane < NU ? dinv_n * y_n : 0.0;
+            double xn = (csrc && lane < NX) ? cs * cdy_n : 0.0;
             {
-                const ldsd *colp = Lm + (lane < NU ? lane : 0); // column `lane` of the block, stride NU
-                const bool on = lane < NU && !mine_fixed;         // a skipped pivot's column is stale
+                const int tn = t + 1 < T ? t + 1 : t;
+                const ldsd *colp = S.Lm + tn * LMS + cl;
 #pragma unroll
-                for (int l = 0; l < NX; l++) lx[l] = on ? colp[l * NU] : 0.0;
+                for (int l = 0; l < NX; l++) lx_n[l] = colp[LM_X(NX, NU, l, 0)];
 #pragma unroll
-                for (int i = 0; i < NU; i++) lcol[i] = on ? colp[(NX + i) * NU] : 0.0;
+                for (int i = 1; i < NU; i++) lcol_n[i] = colp[LM_U(NX, NU, i, 0)];
+                dinv_n = S.dinv[tn * NU + cl];
+                y_n = dw[tn * NZ + NX + cl];
+                cdy_n = csrc ? csrc[tn * NX + pl] : 0.0;
             }
-            double cur = lane < NU ? S.dinv[t * NU + lane] * S.mus[t * NU + lane] : 0.0;
-            const double cdy = (csrc && lane < NX) ? cs * csrc[t * NX + lane] : 0.0;
-            double xn = cdy;
 #pragma unroll
             for (int l = 0; l < NX; l++) {
                 const double xl = bcast(xr, l);
@@ -1387,7 +1434,6 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.e = take(M);
         const int nxs = nx * (nx + 1) / 2;
         S.Lm = take(T * LM_STAGE(nx, nu)); S.dinv = take(T * nu); S.Pr = take((T + 1) * nxs);
-        S.mus = take(T * nu);
         S.rd = take(n); S.rdyn = take(T * nx); S.edyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         // the second direction is dead while a factorisation runs: its storage doubles as the
@@ -1462,6 +1508,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     }
 }
 
+#ifndef HMPC_KERNEL_ONLY // (defined by the one-instantiation probe used to inspect the generated code)
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
 // nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries), with the
 // row slots of their horizons and 1 / 2 / 4 waves per node, and the generic run-time-sized kernel.
@@ -1502,3 +1549,4 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
     if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 2>, 2};
     return {hmpc_qp_kernel<0, 0, 0, 0, 4>, 4};
 }
+#endif
