@@ -165,6 +165,17 @@ def main():
         value = world * B * args.steps / elapsed
         achieved = bytes_per_qp * B / (kernel_ms * 1e-3) / 1e9
         grid, lds = ctrl.qp.launch_info()
+        # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE x2 + WRITE_SIZE, gfx950
+        # corrections of MI355X_MICROARCH.md); counters need their own rocprofv3 runs, so the figure is read
+        # from the committed summary (profiles/collect.sh + profiles/summarise.py), valid for the default frontier
+        traffic, traffic_src = None, None
+        try:
+            if B == 4096 and args.p_one == 0.5:
+                with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as fh:
+                    traffic = json.load(fh)['hbm_traffic_bytes_per_launch']
+                traffic_src = 'profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier',
             'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -174,9 +185,10 @@ def main():
                                    'p_one=%.2f' % args.p_one,
                        'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist(), 'parallelism': 'frontier sharded by node, '
                        'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
-                       'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, 1 refinement step'},
+                       'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                         'algorithmic_bytes_per_launch': bytes_per_qp * B,
                          'algorithmic_bytes_per_qp': bytes_per_qp, 'kernel': 'hmpc_qp_kernel',
                          'kernel_ms_avg': kernel_ms, 'grid': grid, 'lds_bytes_per_wg': lds},
             'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
