@@ -31,8 +31,15 @@ static int fail(int code, const std::string &msg)
             return fail(HMPC_EDEVICE, std::string(#call) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve and resident-node count
+    hmpc_kernel_choice k{};
+    size_t lds = 0;
+    int max_grid = 0;
+};
+
 struct hmpc_handle {
     int device = 0;
+    hmpc_cfg cfg[3];
     DevProb dp{};
     std::vector<void *> allocs;
     double *rows_ws = nullptr;
@@ -176,6 +183,24 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     build_stage(*q, q->F, q->G, q->h, q->nc, reg);
     p.mreg_magic = (unsigned)((0x100000000ULL + p.mreg - 1) / p.mreg);
     p.nnz0 = (int)reg.rcol.size();
+    // columns of the stage rows padded to a fixed stride (compile-time shapes: static column products)
+    std::vector<double> ccv((size_t)nz * HMPC_KC_STRIDE, 0.0);
+    std::vector<int> cci((size_t)nz * HMPC_KC_STRIDE, 0);
+    p.kcol = 0;
+    for (int j = 0; j < nz; j++) {
+        const int len = reg.cptr[j + 1] - reg.cptr[j];
+        if (len > p.kcol) p.kcol = len;
+        for (int k = 0; k < len && k < HMPC_KC_STRIDE; k++) {
+            ccv[(size_t)j * HMPC_KC_STRIDE + k] = reg.cval[reg.cptr[j] + k];
+            cci[(size_t)j * HMPC_KC_STRIDE + k] = reg.crow[reg.cptr[j] + k];
+        }
+    }
+    p.static_rows = (p.kcol <= HMPC_KC_STRIDE && p.mreg <= 255) ? 1 : 0;
+    for (int r = 0; r < q->nc; r++) {
+        int cnt = 0;
+        for (int j = 0; j < nu; j++) cnt += reg.C[(size_t)r * nz + nx + j] != 0.0;
+        if (cnt > 2) p.static_rows = 0;
+    }
     p.nng0 = (int)reg.grow.size();
     // The first nc rows of [F_Tm1 G_Tm1 | h_Tm1] must be the stage rows [F G | h] (controller.py:85-87):
     // the last stage then shares the stage lists and only the terminal-set rows are kept apart.
@@ -229,6 +254,9 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     int rc = HMPC_OK;
     do {
         if ((rc = upload_stage(h, reg, p.reg))) break;
+        if ((rc = upload(h, reg.C, &p.Creg))) break;
+        if ((rc = upload(h, ccv, &p.ccv))) break;
+        if ((rc = upload(h, cci, &p.cci))) break;
         if ((rc = upload(h, Ct, &p.Ct))) break;
         if ((rc = upload(h, ht, &p.ht))) break;
         if ((rc = upload(h, sct, &p.sct))) break;
@@ -245,29 +273,35 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     if (rc) { hmpc_destroy(h); return rc; }
 
     // launch geometry: one 64-lane workgroup per node in flight, as many per CU as LDS admits
-    h->lds = hmpc_lds_bytes(p);
     int cus = 0, lds_max = 0;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
     const size_t lds_cu = 160 * 1024;
     if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
-    if (h->lds > lds_cu || (lds_max > 0 && h->lds > (size_t)lds_max)) {
-        char msg[256];
-        snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", h->lds, lds_max);
-        hmpc_destroy(h);
-        return fail(HMPC_ETOOBIG, msg);
-    }
-    for (int nw = 1; nw <= 4; nw *= 2)
-        if (hipFuncSetAttribute((const void *)hmpc_pick_kernel(p, nw).fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) {
+    // one kernel per number of waves per node; each has its own LDS carve and resident-node count
+    const char *env = getenv("HMPC_BLOCKS_PER_CU");
+    for (int c = 0; c < 3; c++) {
+        hmpc_cfg &cf = h->cfg[c];
+        cf.k = hmpc_pick_kernel(p, 1 << c);
+        cf.lds = hmpc_lds_bytes(p, cf.k.kc);
+        if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max);
+            hmpc_destroy(h);
+            return fail(HMPC_ETOOBIG, msg);
+        }
+        if (hipFuncSetAttribute((const void *)cf.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess) {
             hmpc_destroy(h);
             return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
         }
-    int per_cu = (int)(lds_cu / h->lds);
-    if (per_cu > 8) per_cu = 8;
-    const char *env = getenv("HMPC_BLOCKS_PER_CU");
-    if (env && atoi(env) > 0) per_cu = atoi(env);
-    h->max_grid = (cus > 0 ? cus : 256) * per_cu;
-    if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 5 * p.Mpad * sizeof(double)) != hipSuccess) {
+        int per_cu = (int)(lds_cu / cf.lds);
+        if (per_cu > 8) per_cu = 8;
+        if (env && atoi(env) > 0) per_cu = atoi(env);
+        cf.max_grid = (cus > 0 ? cus : 256) * per_cu;
+        if (cf.max_grid > h->max_grid) h->max_grid = cf.max_grid;
+    }
+    h->lds = h->cfg[0].lds;
+    if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 4 * p.Mpad * sizeof(double)) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
     }
@@ -317,10 +351,13 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
-    const int grid = B < h->max_grid ? B : h->max_grid;
+    const int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
+    const hmpc_cfg &cf = h->cfg[nw == 1 ? 0 : nw == 2 ? 1 : 2];
+    const hmpc_kernel_choice &k = cf.k;
+    const int grid = B < cf.max_grid ? B : cf.max_grid;
     h->last_grid = grid;
-    const hmpc_kernel_choice k = hmpc_pick_kernel(h->dp, hmpc_waves_for(B, h->max_grid));
-    hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), h->lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
+    h->lds = cf.lds;
+    hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace);
     HIPCHK(hipGetLastError());
     return HMPC_OK;

@@ -20,11 +20,18 @@ struct SparseStage {
     const double *scale;       // mg row scales
 };
 
+#define HMPC_KC_STRIDE 16
+
 struct DevProb {
     int nx, nu, nub, nuc, nz, T, nc, ncL, nT, mreg, Toff, M, Mpad, n, ne, nq, nr, nqT, n_primal, n_dual;
     unsigned mreg_magic;                       // ceil(2^32 / mreg): r / mreg == umulhi(r, magic) for r < 2^16
     int nnz0, nng0;                            // nonzeros / Gram terms of the regular stage (staged in LDS)
     SparseStage reg;                           // stage rows: [F G] (nc) then the bounds of the binaries (2 nub)
+    const double *Creg;                        // the same rows as a dense mreg x nz matrix
+    const double *ccv;                         // columns of the stage rows padded to HMPC_KC_STRIDE (value, local row)
+    const int *cci;
+    int kcol;                                  // longest column of the stage rows
+    int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
     const int *ei, *ej;                        // lower-triangle entry -> (i, j)
@@ -39,11 +46,12 @@ struct DevOut {
     double *primal, *dual;
 };
 
-// LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).
-static inline size_t hmpc_lds_bytes(const DevProb &p)
+// LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).  kc: entries per padded column of
+// the kernel's compile-time shape (Dims::kKC), 0 for the generic kernel.
+static inline size_t hmpc_lds_bytes(const DevProb &p, int kc)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
-    size_t d = 0, i = 0;
+    size_t d = 0, i = 0, b = 0;
     const size_t nxs = nx * (nx + 1) / 2, lms = nx * nu + nu * (nu - 1) / 2;
     const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
     d += dir;                                                             // w lam nuf
@@ -54,10 +62,17 @@ static inline size_t hmpc_lds_bytes(const DevProb &p)
     d += nx + nz + 40;                                                    // q mv red
     d += nx;                                                              // x0
     d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
-    d += p.mreg + 2 * (size_t)p.nnz0 + p.nng0;                            // h0 rval0 cval0 gval0
     i += 2 + T * nub + 2 * (size_t)p.ne;                                  // flag fix ei ej
-    i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0 + (p.ne + 1) + p.nng0; // rptr0 rcol0 cptr0 crow0 gptr0 grow0
-    return d * sizeof(double) + i * sizeof(int);
+    i += (p.ne + 1) + p.nng0;                                             // gptr0 grow0
+    d += p.mreg + p.nng0;                                                 // h0 gval0
+    if (kc > 0) {
+        d += nz * (size_t)kc;                                             // padded column values
+        b += (nz * (size_t)kc + 3) / 4 * 4;                               // padded column rows (bytes)
+    } else {
+        d += 2 * (size_t)p.nnz0;                                          // rval0 cval0
+        i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0;                   // rptr0 rcol0 cptr0 crow0
+    }
+    return d * sizeof(double) + i * sizeof(int) + b;
 }
 
 #endif

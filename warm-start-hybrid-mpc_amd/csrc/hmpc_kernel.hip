@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "hmpc_device.h"
 
@@ -130,6 +131,7 @@ DEV double bcast(double v, int src)
 // pointer would compile to flat_load: slower, and it ties up both memory counters).
 typedef __attribute__((address_space(3))) double ldsd;
 typedef __attribute__((address_space(3))) int ldsi;
+typedef __attribute__((address_space(3))) unsigned char ldsb;
 
 // Sparse lists of one stage type, resident in LDS (regular stage) or in global memory (last stage).
 template <class IP, class DP>
@@ -153,6 +155,8 @@ struct Lds {
     ldsd *AB, *P, *PT; // [A B] (nx x nz), scaled cost Hessians
     ldsi *ei, *ej;     // lower-triangle entry -> (i, j)
     ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
+    const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
+    const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
 };
 
@@ -162,6 +166,9 @@ template <int NX_, int NU_, int NUB_, int NW_>
 struct Dims {
     static constexpr int kNX = NX_, kNU = NU_, kNUB = NUB_;
     static constexpr int kNW = NW_, kNT = NW_ * 64; // waves / threads per node (workgroup)
+    // entries per padded column of the stage rows (compile-time shapes): the cart-pole systems have at
+    // most 14 (nu = 7) and 8 (nu = 4); a problem of the same shape with fuller columns takes the generic kernel
+    static constexpr int kKC = NX_ > 0 ? (NU_ == 7 ? 14 : 8) : 0;
     static DEV int nx(const DevProb &p) { return NX_ > 0 ? NX_ : p.nx; }
     static DEV int nu(const DevProb &p) { return NU_ > 0 ? NU_ : p.nu; }
     static DEV int nub(const DevProb &p) { return NU_ > 0 ? NUB_ : p.nub; }
@@ -170,42 +177,46 @@ struct Dims {
     static DEV int ne(const DevProb &p) { return NX_ > 0 ? (NX_ + NU_) * (NX_ + NU_ + 1) / 2 : p.ne; }
 };
 
-// Per-row values that only the owning lane touches (row r <-> lane r % 64, slot k = r / 64):
-// slack s, multiplier z, barrier weight D = z/s (0 on inactive rows), combined step dz, affine
-// product / slack step prod.  Row residuals and the constant direction's dz are recomputed from
-// the stage vectors when needed (a sparse row dot each) instead of being stored.
+// Per-row values that only the owning lane touches: slack s, multiplier z, combined step dz, affine
+// product / slack step prod.  The barrier weight D = z/s (0 on inactive rows) SHARES the storage of z:
+// from the factorisation of an iteration to its update the slot holds D (and z is D * s wherever it is
+// needed), otherwise it holds z.  Row residuals and the constant direction's dz are recomputed from
+// the stage vectors when needed (a row product each) instead of being stored.
 // RS > 0: RS slots per lane, kept in registers (every loop over slots is fully unrolled so the
 // arrays are statically indexed).  RS == 0: run-time number of slots, kept in a per-workgroup slab
 // of global memory (coalesced, L2 resident) -- the generic kernel.
 template <int RS>
 struct Rows {
-    double s_[RS], z_[RS], D_[RS], dz_[RS], prod_[RS];
+    double s_[RS], zd_[RS], dz_[RS], prod_[RS];
     DEV double &s(int k, int) { return s_[k]; }
-    DEV double &z(int k, int) { return z_[k]; }
-    DEV double &D(int k, int) { return D_[k]; }
+    DEV double &z(int k, int) { return zd_[k]; }
+    DEV double &D(int k, int) { return zd_[k]; }
     DEV double &dz(int k, int) { return dz_[k]; }
     DEV double &prod(int k, int) { return prod_[k]; }
     DEV void bind(double *, int) {}
 };
 template <>
 struct Rows<0> {
-    double *__restrict__ s_, *__restrict__ z_, *__restrict__ D_, *__restrict__ dz_, *__restrict__ prod_;
+    double *__restrict__ s_, *__restrict__ zd_, *__restrict__ dz_, *__restrict__ prod_;
     DEV double &s(int, int r) { return s_[r]; }
-    DEV double &z(int, int r) { return z_[r]; }
-    DEV double &D(int, int r) { return D_[r]; }
+    DEV double &z(int, int r) { return zd_[r]; }
+    DEV double &D(int, int r) { return zd_[r]; }
     DEV double &dz(int, int r) { return dz_[r]; }
     DEV double &prod(int, int r) { return prod_[r]; }
-    DEV void bind(double *base, int Mpad) { s_ = base; z_ = base + Mpad; D_ = base + 2 * Mpad; dz_ = base + 3 * Mpad; prod_ = base + 4 * Mpad; }
+    DEV void bind(double *base, int Mpad) { s_ = base; zd_ = base + Mpad; dz_ = base + 2 * Mpad; prod_ = base + 3 * Mpad; }
 };
-// loop over the rows of this lane: slot k, row r.  The row index is made opaque to the optimiser in
-// every loop: otherwise everything derived from it (stage, local row, a dozen addresses per slot) is
-// hoisted out of the interior-point loop for all slots at once and spills to scratch memory.
+// Loop over the rows of this lane: slot k, row handle rw (from the row map rm; rw.e is the row's index in
+// S.e and in the slab).  The lane-dependent part of the handle is made opaque to the optimiser in every
+// loop: otherwise everything derived from it (stage, local row, a dozen addresses per slot) is hoisted
+// out of the interior-point loop for all slots at once and spills to scratch memory.
 #define ROW_OPAQUE(r) asm volatile("" : "+v"(r))
-#define ROWS_BEGIN(k, r)                                   \
+// The same for the thread index at the entry of a phase: addresses derived from it are recomputed per
+// phase (a few integer operations) instead of being kept in registers across the whole iteration.
+#define LANE_OPAQUE(lane) asm volatile("" : "+v"(lane))
+#define ROWS_BEGIN(k, rw)                                  \
     _Pragma("unroll") for (int k = 0; k < nslot; k++) {   \
-        int r = k * D::kNT + lane;                         \
-        ROW_OPAQUE(r);                                     \
-        if (r < M) {
+        typename RM::Ref rw;                               \
+        if (rm.at(p, k, lane, rw)) {
 #define ROWS_END }}
 
 // Row r -> (stage t, local row lr).  Rows [0, T*mreg) are the stage rows, mreg per stage; the
@@ -282,7 +293,38 @@ template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, c
 }
 template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, int j, const ldsd *base)
 {
-    double a = col_dot(S.L0, j, base + t * p.mreg);
+    double a;
+    if constexpr (D::kKC > 0) {
+        // padded column: a fixed number of (value, row) pairs, all loads independent of each other
+        const ldsd *eb = base + t * p.mreg, *cv = S.ccv + j * D::kKC;
+        const ldsb *ci = S.cci + j * D::kKC;
+        // two batches: all loads of a batch are issued before its first product (the scheduling fences keep
+        // the compiler from pairing every load with its use, which would expose one LDS round trip per term)
+        constexpr int H = D::kKC / 2;
+        static_assert(D::kKC % 2 == 0, "padded columns come in two halves");
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for (int hb = 0; hb < D::kKC; hb += H) {
+            int idx[H];
+            double cc[H], ee[H];
+#pragma unroll
+            for (int q = 0; q < H; q++) idx[q] = ci[hb + q];
+#pragma unroll
+            for (int q = 0; q < H; q++) cc[q] = cv[hb + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < H; q++) ee[q] = eb[idx[q]];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < H; q++) {
+                if (q & 1) a1 += cc[q] * ee[q];
+                else a0 += cc[q] * ee[q];
+            }
+        }
+        a = a0 + a1;
+    } else {
+        a = col_dot(S.L0, j, base + t * p.mreg);
+    }
     if (S.term_on && t == p.T - 1) {
         const int nz = D::nz(p);
         const ldsd *vt = base + p.Toff;
@@ -298,6 +340,152 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
     return a;
 }
 DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? S.L0.h[lr] : p.ht[lr - p.mreg]; }
+// ---------------------------------------------------------------------------------------------
+// Row maps: which rows a lane owns and how it evaluates them.
+//
+// RowMapL (generic kernel): rows in stage-major order, row r <-> lane r % kNT, slot r / kNT; every
+// evaluation walks the sparse row list of the stage in LDS (dynamic trip counts, dependent loads).
+//
+// RowMapS (compile-time shapes): a lane owns the SAME local row in every slot, so the row itself lives
+// in registers and a slot only changes the stage:
+//   slots [0, KF)        [F G] rows: lane = tsub * nc + lr, slot k holds stage k * SP + tsub
+//                        (SP = kNT / nc stages per slot); the row is 4 state coefficients and at most
+//                        two input coefficients (checked on the host, DevProb::static_rows)
+//   slots [KF, KF + KB)  bound rows of the binaries: lane = tsub * 2 nub + c, stage kb * SB + tsub
+//   slots [KF + KB, ..)  terminal-set rows (dense, global memory, only in the second solve of a node)
+// A row product is then a handful of LDS loads at addresses known up front: no list, no index loads,
+// no loop -- the loads of all slots are in flight together.
+// ---------------------------------------------------------------------------------------------
+template <class D> struct RowMapL {
+    struct Ref { int e, t, lr; };
+    static constexpr int kSlots = 0;
+    DEV void init(const DevProb &, int) {}
+    DEV void prepare(const DevProb &, const Lds &, int, int) {}
+    DEV bool at(const DevProb &p, int k, int lane, Ref &rw) const
+    {
+        int r = k * D::kNT + lane;
+        ROW_OPAQUE(r);
+        if (r >= p.M) return false;
+        rw.e = r;
+        row_decode(p, r, rw.t, rw.lr);
+        return true;
+    }
+    DEV bool active(const DevProb &p, const Lds &S, int, const Ref &rw) const { return row_active<D>(p, S.fix, rw.t, rw.lr, S.term_on); }
+    DEV double h(const DevProb &p, const Lds &S, int, const Ref &rw) const { return hrow(p, S, rw.lr); }
+    DEV double dot(const DevProb &p, const Lds &S, int, const Ref &rw, const ldsd *vec) const
+    {
+        return crow_dot<D>(p, S, rw.lr, vec + rw.t * D::nz(p));
+    }
+};
+
+template <class D, int KF, int KB, int KT> struct RowMapS {
+    static constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
+    static constexpr int kSlots = KF + KB + KT;
+    static constexpr int SB = D::kNT / (2 * NUB); // stages per slot of bound rows
+    static_assert(D::kNT % (2 * NUB) == 0, "bound rows must tile the workgroup");
+    struct Ref { int e, v, row; };
+    double cx[NX], cu[2], hF, sgB, hB;
+    int uo[2];
+    int SP, sE, sV, tF0, eF0, vF0, tB0, eB0, vB0, bB;
+    bool okF;
+    unsigned act; // bit k: the row of slot k takes part in the current solve
+    DEV void init(const DevProb &p, int lane)
+    {
+        const int nc = p.nc;
+        SP = D::kNT / nc;
+        const int tsub = lane / nc, lr = lane - tsub * nc;
+        okF = tsub < SP;
+        tF0 = tsub; eF0 = tsub * p.mreg + lr; vF0 = tsub * NZ; sE = SP * p.mreg; sV = SP * NZ;
+        const double *c = p.Creg + (size_t)(okF ? lr : 0) * NZ;
+#pragma unroll
+        for (int i = 0; i < NX; i++) cx[i] = c[i];
+        cu[0] = cu[1] = 0.0;
+        uo[0] = uo[1] = NX;
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NU; j++) {
+            const double v = c[NX + j];
+            if (v != 0.0) {
+                if (cnt == 0) { cu[0] = v; uo[0] = NX + j; } else { cu[1] = v; uo[1] = NX + j; }
+                cnt++;
+            }
+        }
+        hF = p.reg.h[okF ? lr : 0];
+        const int cB = lane % (2 * NUB);
+        bB = cB % NUB;
+        tB0 = lane / (2 * NUB);
+        eB0 = tB0 * p.mreg + nc + cB;
+        vB0 = tB0 * NZ + NX + NUC + bB;
+        sgB = p.Creg[(size_t)(nc + cB) * NZ + NX + NUC + bB];
+        hB = p.reg.h[nc + cB];
+        act = 0;
+    }
+    DEV bool at(const DevProb &p, int k, int lane, Ref &rw) const
+    {
+        if (k < KF) {
+            int e0 = eF0, v0 = vF0;
+            ROW_OPAQUE(e0);
+            ROW_OPAQUE(v0);
+            rw.e = e0 + k * sE;
+            rw.v = v0 + k * sV;
+            rw.row = 0;
+            return okF && tF0 + k * SP < p.T;
+        } else if (k < KF + KB) {
+            const int kb = k - KF;
+            int e0 = eB0, v0 = vB0;
+            ROW_OPAQUE(e0);
+            ROW_OPAQUE(v0);
+            rw.e = e0 + kb * SB * p.mreg;
+            rw.v = v0 + kb * SB * NZ;
+            rw.row = 0;
+            return tB0 + kb * SB < p.T;
+        } else {
+            int row = (k - KF - KB) * D::kNT + lane;
+            ROW_OPAQUE(row);
+            rw.row = row;
+            rw.e = p.Toff + row;
+            rw.v = (p.T - 1) * NZ;
+            return row < p.nT;
+        }
+    }
+    // which rows take part in the coming solve: all [F G] rows, the bounds of the free binaries, the
+    // terminal-set rows if term_on
+    DEV void prepare(const DevProb &p, const Lds &S, int lane, int term_on)
+    {
+        act = 0;
+#pragma unroll
+        for (int k = 0; k < kSlots; k++) {
+            bool on;
+            if (k < KF) on = true;
+            else if (k < KF + KB) {
+                const int t = tB0 + (k - KF) * SB;
+                on = t < p.T && S.fix[(t < p.T ? t : 0) * NUB + bB] < 0;
+            } else on = term_on != 0;
+            act |= (on ? 1u : 0u) << k;
+        }
+    }
+    DEV bool active(const DevProb &, const Lds &, int k, const Ref &) const { return (act >> k) & 1u; }
+    DEV double h(const DevProb &p, const Lds &, int k, const Ref &rw) const { return k < KF ? hF : k < KF + KB ? hB : p.ht[rw.row]; }
+    DEV double dot(const DevProb &p, const Lds &, int k, const Ref &rw, const ldsd *vec) const
+    {
+        const ldsd *v = vec + rw.v;
+        if (k < KF) {
+            double a = cx[0] * v[0];
+#pragma unroll
+            for (int i = 1; i < NX; i++) a += cx[i] * v[i];
+            return (a + cu[0] * v[uo[0]]) + cu[1] * v[uo[1]];
+        } else if (k < KF + KB) {
+            return sgB * v[0];
+        } else {
+            const double *c = p.Ct + (size_t)rw.row * NZ;
+            double a = 0;
+#pragma unroll
+            for (int j = 0; j < NZ; j++) a += c[j] * v[j];
+            return a;
+        }
+    }
+};
+
 // (C' D C)(i, j) of stage t: Gram lists of the stage rows, plus the dense terminal block if active
 template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, int e, int i, int j)
 {
@@ -445,6 +633,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
     constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
     const int T = p.T;
     FSTAMP_DECL;
+    LANE_OPAQUE(lane);
     if (lane == 0) S.flag[0] = 0;
     for (int e = lane; e < NX * NX; e += D::kNT) {
         const int i = e / NX, j = e - i * NX;
@@ -470,7 +659,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
         }
         __syncthreads();
         FSTAMP(0);
-        if (lane < WAVE) { // phase 2 (registers, wave 0): assemble the column, prescribe, eliminate
+        if (D::kNW == 1 || lane < WAVE) { // phase 2 (registers, wave 0): assemble the column, prescribe, eliminate
             ldsd *Lm = S.Lm + t * LMS;
             double col[NZ];
             if (lane < NZ) {
@@ -578,8 +767,8 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
 // Generic form: every phase is spread over the threads, a barrier after each; the substitutions take
 // one barrier per pivot.
 // ---------------------------------------------------------------------------------------------
-template <class D, int RS>
-DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS, class RM>
+DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
                    const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf)
 {
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
@@ -673,14 +862,11 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const 
         dlam[o] = -a;
     }
     {
-        const int M = p.M, nslot = RS > 0 ? RS : p.Mpad / D::kNT;
-        ROWS_BEGIN(k, r)
-            const double d = R.D(k, r);
-            if (d != 0.0) { // inactive rows keep e = 0
-                int t, lr;
-                row_decode(p, r, t, lr);
-                S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * nz) - S.e[r];
-            }
+        const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+        ROWS_BEGIN(k, rw)
+            const double d = R.D(k, rw.e);
+            if (d != 0.0) // inactive rows keep e = 0
+                S.e[rw.e] = d * rm.dot(p, S, k, rw, dw) - S.e[rw.e];
         ROWS_END
     }
     __syncthreads();
@@ -708,14 +894,15 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const 
 // column of L_u for the back substitution).  Everything that does not depend on the recursion (C' e)
 // is prepared by all waves before the sweep.  No barrier and no LDS round trip on the critical path.
 // ---------------------------------------------------------------------------------------------
-template <class D, int RS>
-DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS, class RM>
+DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
                        const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
     constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
     const int T = p.T;
     FSTAMP_DECL;
+    LANE_OPAQUE(lane);
     // S.g <- (mb if useb) - (rhs_d + C' e): the part of the stage gradient the recursion does not touch
     for (int o = lane; o < T * NZ; o += D::kNT) {
         const int t = o / NZ, j = o - t * NZ;
@@ -740,11 +927,12 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
     }
     __syncthreads();
     FSTAMP(6);
+    LANE_OPAQUE(lane);
     // Both sweeps are software pipelined: everything stage t reads from LDS does not depend on the
     // recursion and is fetched while stage t +- 1 runs its chain of v_readlane / FMA steps, so that no
     // LDS latency sits on the critical path.  Skipped pivots (fixed binaries) have zero multipliers:
     // their substitution steps are no-ops and need no branch.
-    if (lane < WAVE) { // backward sweep (wave 0)
+    if (D::kNW == 1 || lane < WAVE) { // backward sweep (wave 0)
         double ABcol[NX];
 #pragma unroll
         for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
@@ -793,7 +981,8 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
     }
     __syncthreads();
     FSTAMP(7);
-    if (lane < WAVE) { // forward sweep (wave 0)
+    LANE_OPAQUE(lane);
+    if (D::kNW == 1 || lane < WAVE) { // forward sweep (wave 0)
         double ABrow[NZ];
 #pragma unroll
         for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
@@ -852,6 +1041,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
     }
     __syncthreads();
     FSTAMP(9);
+    LANE_OPAQUE(lane);
     // equality multipliers lam_t = -(P_t x_t + p_t) ; dz = D (C dw) - e
     for (int o = lane; o < (T + 1) * NX; o += D::kNT) {
         const int t = o / NX, i = o - t * NX;
@@ -861,14 +1051,11 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
         dlam[o] = -a;
     }
     {
-        const int M = p.M, nslot = RS > 0 ? RS : p.Mpad / D::kNT;
-        ROWS_BEGIN(k, r)
-            const double d = R.D(k, r);
-            if (d != 0.0) { // inactive rows keep e = 0
-                int t, lr;
-                row_decode(p, r, t, lr);
-                S.e[r] = d * crow_dot<D>(p, S, lr, dw + t * NZ) - S.e[r];
-            }
+        const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+        ROWS_BEGIN(k, rw)
+            const double d = R.D(k, rw.e);
+            if (d != 0.0) // inactive rows keep e = 0
+                S.e[rw.e] = d * rm.dot(p, S, k, rw, dw) - S.e[rw.e];
         ROWS_END
     }
     __syncthreads();
@@ -892,30 +1079,27 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, co
     FSTAMP(10);
 }
 
-template <class D, int RS>
-DEV void kkt_dispatch(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, const ldsd *gsrc, double gs, bool usex0,
+template <class D, int RS, class RM>
+DEV void kkt_dispatch(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
                       const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
-    if constexpr (D::kNX > 0) kkt_solve_reg<D, RS>(p, S, R, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
-    else kkt_solve<D, RS>(p, S, R, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
+    if constexpr (D::kNX > 0) kkt_solve_reg<D, RS>(p, S, R, rm, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
+    else kkt_solve<D, RS>(p, S, R, rm, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
 }
 
 // f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
-template <class D>
-DEV double lin_obj(const DevProb &p, const Lds &S, int lane, const ldsd *lam, const ldsd *nuf, const ldsd *zrow)
+template <class D, class RM>
+DEV double lin_obj(const DevProb &p, const Lds &S, const RM &rm, int lane, const ldsd *lam, const ldsd *nuf, const ldsd *zrow)
 {
     double a = 0;
+    LANE_OPAQUE(lane);
     for (int j = lane; j < D::nx(p); j += D::kNT) a += S.x0[j] * lam[j];
     for (int o = lane; o < p.T * D::nub(p); o += D::kNT)
         if (S.fix[o] == 1) a += nuf[o];
-    for (int r = lane; r < p.M; r += D::kNT) {
-        const double v = zrow[r];
-        if (v != 0.0) {
-            int t, lr;
-            row_decode(p, r, t, lr);
-            a += hrow(p, S, lr) * v;
-        }
-    }
+    const int nslot = RM::kSlots > 0 ? RM::kSlots : p.Mpad / D::kNT;
+    ROWS_BEGIN(k, rw)
+        if (rm.active(p, S, k, rw)) a += rm.h(p, S, k, rw) * zrow[rw.e];
+    ROWS_END
     return a; // per-thread partial sum: the caller reduces it together with its other sums
 }
 
@@ -932,6 +1116,7 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, n = T * nz + nx;
     double acc = 0;
+    LANE_OPAQUE(lane);
     for (int o = lane; o < n; o += D::kNT) {
         const int t = o / nz < T ? o / nz : T;
         const int i = o - t * nz, dim = t < T ? nz : nx;
@@ -945,20 +1130,19 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 
 // One interior-point solve of the node with / without the terminal-set rows.
 // Returns status; tau and the iteration count through references.
-template <class D, int RS>
-DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int term_on, int &iters, double &tau_out,
+template <class D, int RS, class RM>
+DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
                   double *trace)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
     int mact = 0;
-    ROWS_BEGIN(k, r)
-        int t, lr;
-        row_decode(p, r, t, lr);
-        const bool on = row_active<D>(p, S.fix, t, lr, term_on);
+    rm.prepare(p, S, lane, term_on);
+    ROWS_BEGIN(k, rw)
+        const bool on = rm.active(p, S, k, rw);
         mact += on;
-        R.s(k, r) = 1.0;
-        R.z(k, r) = on ? 1.0 : 0.0;
+        R.s(k, rw.e) = 1.0;
+        R.z(k, rw.e) = on ? 1.0 : 0.0;
     ROWS_END
     mact = (int)block_sum<D>((double)mact, S.red, lane);
     for (int i = lane; i < n; i += D::kNT) S.w[i] = 0.0;
@@ -980,9 +1164,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
 #endif
     for (it = 0; it <= p.max_iter; it++) {
         STAMP(7);
+        LANE_OPAQUE(lane);
         // ---------------- residuals ----------------
-        ROWS_BEGIN(k, r)
-            S.e[r] = R.z(k, r); // S.e <- z for the C'z products below
+        ROWS_BEGIN(k, rw)
+            S.e[rw.e] = R.z(k, rw.e); // S.e <- z for the C'z products below
         ROWS_END
         __syncthreads();
         double wPw = 0;
@@ -1028,13 +1213,11 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             rcinf = fmax(rcinf, fabs(a));
         }
         double hz = 0, sz = 0, zinf = 0;
-        ROWS_BEGIN(k, r)
-            int t, lr;
-            row_decode(p, r, t, lr);
+        ROWS_BEGIN(k, rw)
             double a = 0;
-            if (row_active<D>(p, S.fix, t, lr, term_on)) {
-                const double zr = R.z(k, r), sr = R.s(k, r), hh = hrow(p, S, lr);
-                a = sr - hh * tau + crow_dot<D>(p, S, lr, S.w + t * nz);
+            if (rm.active(p, S, k, rw)) {
+                const double zr = R.z(k, rw.e), sr = R.s(k, rw.e), hh = rm.h(p, S, k, rw);
+                a = sr - hh * tau + rm.dot(p, S, k, rw, S.w);
                 hz += hh * zr;
                 sz += sr * zr;
                 zinf = fmax(zinf, zr);
@@ -1089,10 +1272,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
-                ROWS_BEGIN(k, r)
-                    if (R.D(k, r) != 0.0) {
-                        R.z(k, r) -= last_alpha * R.dz(k, r);
-                        R.s(k, r) -= last_alpha * R.prod(k, r);
+                ROWS_BEGIN(k, rw)
+                    if (R.D(k, rw.e) != 0.0) {
+                        R.z(k, rw.e) -= last_alpha * R.dz(k, rw.e);
+                        R.s(k, rw.e) -= last_alpha * R.prod(k, rw.e);
                     }
                 ROWS_END
                 tau -= last_alpha * last_dtau;
@@ -1110,33 +1293,38 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         if (it == p.max_iter) break;
 
         // ---------------- factorisation ----------------
+        LANE_OPAQUE(lane);
         __syncthreads(); // every thread is done reading z from S.e
-        ROWS_BEGIN(k, r)
-            const double zr = R.z(k, r); // zero on inactive rows
-            const double d = zr != 0.0 ? zr / R.s(k, r) : 0.0;
-            R.D(k, r) = d;
-            S.e[r] = d; // S.e <- D for the Gram phase of the factorisation
+        ROWS_BEGIN(k, rw)
+            const double zr = R.z(k, rw.e); // zero on inactive rows
+            const double d = zr != 0.0 ? zr / R.s(k, rw.e) : 0.0;
+            R.D(k, rw.e) = d; // the slot holds D from here to the update of this iteration
+            S.e[rw.e] = d;    // S.e <- D for the Gram phase of the factorisation
         ROWS_END
         __syncthreads();
         STAMP(1);
         int frc;
         if constexpr (D::kNX > 0) frc = factor_reg<D>(p, S, lane FSTAMP_PASS);
         else frc = factor<D>(p, S, lane);
-        if (frc != 0) { if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL; break; }
+        if (frc != 0) {
+            ROWS_BEGIN(k, rw)
+                R.z(k, rw.e) = R.D(k, rw.e) * R.s(k, rw.e); // the slots hold z again
+            ROWS_END
+            if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL;
+            break;
+        }
         STAMP(2);
-        ROWS_BEGIN(k, r)
-            int t, lr;
-            row_decode(p, r, t, lr);
-            S.e[r] = R.D(k, r) * hrow(p, S, lr); // right-hand side of the constant direction
+        ROWS_BEGIN(k, rw)
+            S.e[rw.e] = R.D(k, rw.e) * rm.h(p, S, k, rw); // right-hand side of the constant direction
         ROWS_END
         __syncthreads();
 
         // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-        kkt_dispatch<D, RS>(p, S, R, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+        kkt_dispatch<D, RS>(p, S, R, rm, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
         STAMP(3);
         double g1 = 0;
         g1 = wPv<D>(p, S, lane, S.w1);
-        double fyhz1 = lin_obj<D>(p, S, lane, S.lam1, S.nuf1, S.e);
+        double fyhz1 = lin_obj<D>(p, S, rm, lane, S.lam1, S.nuf1, S.e);
         {
             double v[2] = {g1, fyhz1};
             const int op[2] = {0, 0};
@@ -1149,27 +1337,26 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
         for (int pass = 0; pass < 2; pass++) {
             const double lin = pass == 0 ? 1.0 : 1.0 - sigma;
             const double dkap_rhs = tau * kap + (pass ? dtau_a * dkap_a - sigma * mu : 0.0);
+            LANE_OPAQUE(lane);
             __syncthreads();
-            ROWS_BEGIN(k, r)
+            ROWS_BEGIN(k, rw)
                 double v = 0;
-                const double d = R.D(k, r);
+                const double d = R.D(k, rw.e);
                 if (d != 0.0) { // active row
-                    int t, lr;
-                    row_decode(p, r, t, lr);
-                    const double zr = R.z(k, r), sr = R.s(k, r);
-                    const double rc = sr - hrow(p, S, lr) * tau + crow_dot<D>(p, S, lr, S.w + t * nz); // row residual
-                    const double dsr = sr * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
+                    const double sr = R.s(k, rw.e), zr = d * sr;
+                    const double rc = sr - rm.h(p, S, k, rw) * tau + rm.dot(p, S, k, rw, S.w); // row residual
+                    const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
                     v = d * (-lin * rc + dsr / zr);
                 }
-                S.e[r] = v;
+                S.e[rw.e] = v;
             ROWS_END
             __syncthreads();
             STAMP(4);
-            kkt_dispatch<D, RS>(p, S, R, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
+            kkt_dispatch<D, RS>(p, S, R, rm, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
             STAMP(3);
             double g2 = 0;
             g2 = wPv<D>(p, S, lane, S.w2);
-            double fyhz2 = lin_obj<D>(p, S, lane, S.lam2, S.nuf2, S.e);
+            double fyhz2 = lin_obj<D>(p, S, rm, lane, S.lam2, S.nuf2, S.e);
             {
                 double v[2] = {g2, fyhz2};
                 const int op[2] = {0, 0};
@@ -1182,18 +1369,16 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             for (int o = lane; o < n; o += D::kNT) S.w2[o] += dtau * S.w1[o];
             for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += dtau * S.lam1[o];
             for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += dtau * S.nuf1[o];
-            ROWS_BEGIN(k, r)
+            ROWS_BEGIN(k, rw)
                 double v = 0.0;
-                const double d = R.D(k, r);
+                const double d = R.D(k, rw.e);
                 if (d != 0.0) {
-                    int t, lr;
-                    row_decode(p, r, t, lr);
                     // multiplier step of the constant direction: D (C w1 - h)
-                    const double z1 = d * (crow_dot<D>(p, S, lr, S.w1 + t * nz) - hrow(p, S, lr));
-                    v = S.e[r] + dtau * z1;
+                    const double z1 = d * (rm.dot(p, S, k, rw, S.w1) - rm.h(p, S, k, rw));
+                    v = S.e[rw.e] + dtau * z1;
                 }
-                S.e[r] = v;
-                R.dz(k, r) = v;
+                S.e[rw.e] = v;
+                R.dz(k, rw.e) = v;
             ROWS_END
             __syncthreads();
             // Iterative refinement against the three linear blocks of the Newton system at this dtau:
@@ -1202,9 +1387,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
             // tolerance for the trajectory to be accurate to 1e-5).
             const int nref = (pass == 1 && p.refine) ? (mu < 1e-7 ? 2 : mu < 1e-3 ? 1 : 0) : 0;
             for (int rf = 0; rf < nref; rf++) {
+                LANE_OPAQUE(lane);
                 if (rf > 0) { // S.e <- current dz for the C' dz products (the previous round left its correction there)
-                    ROWS_BEGIN(k, r)
-                        S.e[r] = R.dz(k, r);
+                    ROWS_BEGIN(k, rw)
+                        S.e[rw.e] = R.dz(k, rw.e);
                     ROWS_END
                     __syncthreads();
                 }
@@ -1234,45 +1420,43 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                     S.edyn[o] = a;
                 }
                 __syncthreads();
-                ROWS_BEGIN(k, r)
+                ROWS_BEGIN(k, rw)
                     double v = 0;
-                    const double d = R.D(k, r);
+                    const double d = R.D(k, rw.e);
                     if (d != 0.0) {
-                        int t, lr;
-                        row_decode(p, r, t, lr);
-                        const double zr = R.z(k, r), sr = R.s(k, r);
-                        const double rc = sr - hrow(p, S, lr) * tau + crow_dot<D>(p, S, lr, S.w + t * nz);
-                        const double dsr = sr * zr + R.prod(k, r) - sigma * mu;
-                        const double a = -lin * rc + dsr / zr + dtau * hrow(p, S, lr) + S.e[r] * sr / zr -
-                                         crow_dot<D>(p, S, lr, S.w2 + t * nz);
+                        const double sr = R.s(k, rw.e), zr = d * sr, hh = rm.h(p, S, k, rw);
+                        const double rc = sr - hh * tau + rm.dot(p, S, k, rw, S.w);
+                        const double dsr = sr * zr + R.prod(k, rw.e) - sigma * mu;
+                        const double a = -lin * rc + dsr / zr + dtau * hh + S.e[rw.e] * sr / zr - rm.dot(p, S, k, rw, S.w2);
                         v = d * a;
                     }
-                    S.e[r] = v;
+                    S.e[rw.e] = v;
                 ROWS_END
                 __syncthreads();
                 STAMP(5);
-                kkt_dispatch<D, RS>(p, S, R, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+                kkt_dispatch<D, RS>(p, S, R, rm, lane, S.g, 1.0, false, S.edyn, 1.0, false, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
                 STAMP(3);
                 for (int o = lane; o < n; o += D::kNT) S.w2[o] += S.w1[o];
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam2[o] += S.lam1[o];
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf2[o] += S.nuf1[o];
-                ROWS_BEGIN(k, r)
-                    if (R.D(k, r) != 0.0) R.dz(k, r) += S.e[r];
+                ROWS_BEGIN(k, rw)
+                    if (R.D(k, rw.e) != 0.0) R.dz(k, rw.e) += S.e[rw.e];
                 ROWS_END
             }
             // slack step from the complementarity row ; step to the boundary
+            LANE_OPAQUE(lane);
             double amax = 1e30;
             if (dtau < 0) amax = fmin(amax, -tau / dtau);
             if (dkap < 0) amax = fmin(amax, -kap / dkap);
-            ROWS_BEGIN(k, r)
-                if (R.D(k, r) != 0.0) {
-                    const double dz = R.dz(k, r), sr = R.s(k, r), zr = R.z(k, r);
-                    const double dsr = sr * zr + (pass ? R.prod(k, r) - sigma * mu : 0.0);
+            ROWS_BEGIN(k, rw)
+                if (R.D(k, rw.e) != 0.0) {
+                    const double dz = R.dz(k, rw.e), sr = R.s(k, rw.e), zr = R.D(k, rw.e) * sr;
+                    const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
                     const double ds = -(dsr + sr * dz) / zr;
                     if (dz < 0) amax = fmin(amax, -zr / dz);
                     if (ds < 0) amax = fmin(amax, -sr / ds);
-                    if (pass == 0) R.prod(k, r) = ds * dz;
-                    else R.prod(k, r) = ds; // the affine product is consumed: keep the slack step here (also for an undo)
+                    if (pass == 0) R.prod(k, rw.e) = ds * dz;
+                    else R.prod(k, rw.e) = ds; // the affine product is consumed: keep the slack step here (also for an undo)
                 }
             ROWS_END
             amax = block_min<D>(amax, S.red, lane);
@@ -1287,10 +1471,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, int lane, int ter
                 for (int o = lane; o < n; o += D::kNT) S.w[o] += alpha * S.w2[o];
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] += alpha * S.lam2[o];
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] += alpha * S.nuf2[o];
-                ROWS_BEGIN(k, r)
-                    if (R.D(k, r) != 0.0) {
-                        R.z(k, r) += alpha * R.dz(k, r);
-                        R.s(k, r) += alpha * R.prod(k, r);
+                ROWS_BEGIN(k, rw)
+                    if (R.D(k, rw.e) != 0.0) { // the slot holds z again from here on
+                        R.z(k, rw.e) = R.D(k, rw.e) * R.s(k, rw.e) + alpha * R.dz(k, rw.e);
+                        R.s(k, rw.e) += alpha * R.prod(k, rw.e);
                     }
                 ROWS_END
                 tau += alpha * dtau;
@@ -1416,13 +1600,18 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
     }
 }
 
-template <int NX_, int NU_, int NUB_, int RS, int NW>
+// KF / KB / KT: register slots of the static row map ([F G] rows, bound rows, terminal-set rows) for the
+// compile-time shapes; all zero for the generic kernel (list row map, rows in the global slab).
+template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW>
 __global__ void __launch_bounds__(NW * WAVE)
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Dims<NX_, NU_, NUB_, NW> D;
+    constexpr int RS = KF + KB + KT;
+    static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernel the lists");
+    typedef typename std::conditional<(NX_ > 0), RowMapS<D, KF, KB, KT>, RowMapL<D>>::type RM;
     const int lane = threadIdx.x; // thread of the workgroup; wave 0 (lane < 64) runs the recursions
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M, n = T * nz + nx, ne = D::ne(p);
     Lds S;
@@ -1444,14 +1633,19 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.q = take(nx); S.mv = take(nz); S.red = take(40);
         S.x0 = take(nx);
         S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
-        ldsd *h0 = take(p.mreg), *rval0 = take(p.nnz0), *cval0 = take(p.nnz0), *gval0 = take(p.nng0);
+        // lists of the regular stage: the generic kernel stages rows, columns and Gram lists; the
+        // compile-time shapes padded columns and Gram lists (their rows live in registers)
+        constexpr int KC = D::kKC;
+        ldsd *h0 = take(p.mreg), *rval0 = take(KC ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : p.nnz0), *gval0 = take(p.nng0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
         S.flag = takei(2);
         S.fix = takei(T * nub);
         S.ei = takei(ne); S.ej = takei(ne);
-        ldsi *rptr0 = takei(p.mreg + 1), *rcol0 = takei(p.nnz0), *cptr0 = takei(nz + 1), *crow0 = takei(p.nnz0);
+        ldsi *rptr0 = takei(KC ? 0 : p.mreg + 1), *rcol0 = takei(KC ? 0 : p.nnz0), *cptr0 = takei(KC ? 0 : nz + 1);
+        ldsi *crow0 = takei(KC ? 0 : p.nnz0);
         ldsi *gptr0 = takei(ne + 1), *grow0 = takei(p.nng0);
+        ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
         for (int i = lane; i < nx * nz; i += D::kNT) {
@@ -1461,17 +1655,29 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int i = lane; i < nz * nz; i += D::kNT) S.P[i] = p.P[i];
         for (int i = lane; i < nx * nx; i += D::kNT) S.PT[i] = p.PT[i];
         for (int i = lane; i < p.mreg; i += D::kNT) h0[i] = g0.h[i];
-        for (int i = lane; i < p.nnz0; i += D::kNT) { rval0[i] = g0.rval[i]; cval0[i] = g0.cval[i]; rcol0[i] = g0.rcol[i]; crow0[i] = g0.crow[i]; }
+        if constexpr (KC > 0) {
+            for (int i = lane; i < nz * KC; i += D::kNT) {
+                const int j = i / KC, qq = i - j * KC;
+                cval0[i] = p.ccv[j * HMPC_KC_STRIDE + qq];
+                cci0[i] = (unsigned char)p.cci[j * HMPC_KC_STRIDE + qq];
+            }
+        } else {
+            for (int i = lane; i < p.nnz0; i += D::kNT) { rval0[i] = g0.rval[i]; cval0[i] = g0.cval[i]; rcol0[i] = g0.rcol[i]; crow0[i] = g0.crow[i]; }
+            for (int i = lane; i < p.mreg + 1; i += D::kNT) rptr0[i] = g0.rptr[i];
+            for (int i = lane; i < nz + 1; i += D::kNT) cptr0[i] = g0.cptr[i];
+        }
         for (int i = lane; i < p.nng0; i += D::kNT) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
-        for (int i = lane; i < p.mreg + 1; i += D::kNT) rptr0[i] = g0.rptr[i];
-        for (int i = lane; i < nz + 1; i += D::kNT) cptr0[i] = g0.cptr[i];
         for (int i = lane; i < ne + 1; i += D::kNT) gptr0[i] = g0.gptr[i];
         for (int i = lane; i < ne; i += D::kNT) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
+        S.ccv = cval0;
+        S.cci = cci0;
         S.term_on = 0;
     }
     Rows<RS> R;
-    R.bind(rows_ws + (size_t)blockIdx.x * 5 * p.Mpad, p.Mpad);
+    R.bind(rows_ws + (size_t)blockIdx.x * 4 * p.Mpad, p.Mpad);
+    RM rm;
+    rm.init(p, lane);
     for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
         __syncthreads();
         for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
@@ -1487,7 +1693,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS>(p, S, R, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
+            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -1498,8 +1704,8 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         __syncthreads();
         {
             const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
-            ROWS_BEGIN(k, r)
-                S.e[r] = R.z(k, r);
+            ROWS_BEGIN(k, rw)
+                S.e[rw.e] = R.z(k, rw.e);
             ROWS_END
         }
         __syncthreads();
@@ -1516,6 +1722,7 @@ typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *
 struct hmpc_kernel_choice {
     hmpc_kernel_t fn;
     int waves;
+    int kc; // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
 };
 // Waves per node: measured on MI355X (cart-pole N=20) one wave per node gives the best throughput
 // once every CU holds its three nodes (221 k QP/s at 4096 nodes vs 184 k / 138 k with 2 / 4 waves),
@@ -1531,22 +1738,43 @@ static int hmpc_waves_for(int B, int resident_nodes)
     if (B <= 2 * resident_nodes) return 2;
     return 1;
 }
+// Slots the static row map needs for this problem with nw waves per node (see RowMapS).
+static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &kt)
+{
+    const int nt = nw * WAVE;
+    if (!p.static_rows || p.nc < 1 || p.nc > nt || p.nub < 1 || nt % (2 * p.nub) != 0) return false;
+    const int sp = nt / p.nc, sb = nt / (2 * p.nub);
+    kf = (p.T + sp - 1) / sp;
+    kb = (p.T + sb - 1) / sb;
+    kt = (p.nT + nt - 1) / nt;
+    return true;
+}
+#define HMPC_TRY(NX, NU, NUB, F, Bn, Tn, NWv) \
+    if (kf <= F && kb <= Bn && kt <= Tn && p.kcol <= Dims<NX, NU, NUB, NWv>::kKC)       \
+        return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, NWv, Dims<NX, NU, NUB, NWv>::kKC};
 static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
 {
     const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr;
-    const int slots = (p.M + nw * WAVE - 1) / (nw * WAVE);
+    int kf = 0, kb = 0, kt = 0;
     if (!generic && p.nx == 4 && p.nu == 7 && p.nub == 4) {
-        if (nw == 1) return {slots <= 8 ? hmpc_qp_kernel<4, 7, 4, 8, 1> : slots <= 13 ? hmpc_qp_kernel<4, 7, 4, 13, 1> : hmpc_qp_kernel<4, 7, 4, 0, 1>, 1};
-        if (nw == 2) return {slots <= 4 ? hmpc_qp_kernel<4, 7, 4, 4, 2> : slots <= 7 ? hmpc_qp_kernel<4, 7, 4, 7, 2> : slots <= 13 ? hmpc_qp_kernel<4, 7, 4, 13, 2> : hmpc_qp_kernel<4, 7, 4, 0, 2>, 2};
-        return {slots <= 4 ? hmpc_qp_kernel<4, 7, 4, 4, 4> : slots <= 7 ? hmpc_qp_kernel<4, 7, 4, 7, 4> : hmpc_qp_kernel<4, 7, 4, 0, 4>, 4};
+        // smallest instantiation that holds the rows; fewer waves than asked for never fit more rows
+        for (int w = nw; w <= 4; w *= 2) {
+            if (!hmpc_static_slots(p, w, kf, kb, kt)) continue;
+            if (w == 1) { HMPC_TRY(4, 7, 4, 10, 3, 2, 1) }
+            if (w == 2) { HMPC_TRY(4, 7, 4, 5, 2, 1, 2) HMPC_TRY(4, 7, 4, 10, 3, 1, 2) }
+            if (w == 4) { HMPC_TRY(4, 7, 4, 3, 1, 1, 4) HMPC_TRY(4, 7, 4, 5, 2, 1, 4) }
+        }
     }
     if (!generic && p.nx == 4 && p.nu == 4 && p.nub == 2) {
-        if (nw == 1) return {hmpc_qp_kernel<4, 4, 2, 0, 1>, 1};
-        if (nw == 2) return {slots <= 8 ? hmpc_qp_kernel<4, 4, 2, 8, 2> : hmpc_qp_kernel<4, 4, 2, 0, 2>, 2};
-        return {slots <= 4 ? hmpc_qp_kernel<4, 4, 2, 4, 4> : hmpc_qp_kernel<4, 4, 2, 0, 4>, 4};
+        for (int w = nw < 2 ? 2 : nw; w <= 4; w *= 2) {
+            if (!hmpc_static_slots(p, w, kf, kb, kt)) continue;
+            if (w == 2) { HMPC_TRY(4, 4, 2, 7, 2, 1, 2) }
+            if (w == 4) { HMPC_TRY(4, 4, 2, 4, 1, 1, 4) }
+        }
     }
-    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 1>, 1};
-    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 2>, 2};
-    return {hmpc_qp_kernel<0, 0, 0, 0, 4>, 4};
+    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, 1, 0};
+    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, 2, 0};
+    return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, 4, 0};
 }
+#undef HMPC_TRY
 #endif
