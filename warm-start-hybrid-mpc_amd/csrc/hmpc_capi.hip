@@ -249,6 +249,25 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     std::vector<int> ei, ej;
     for (int i = 0; i < nz; i++)
         for (int j = 0; j <= i; j++) { ei.push_back(i); ej.push_back(j); }
+    // Number the entries with a nonempty Gram list first (the register factorisation gives one lane
+    // to each of them); the lists follow the same numbering.
+    {
+        std::vector<int> order;
+        for (int pass = 0; pass < 2; pass++)
+            for (int e = 0; e < p.ne; e++)
+                if ((reg.gptr[e + 1] > reg.gptr[e]) == (pass == 0)) order.push_back(e);
+        p.ngram = 0;
+        for (int e = 0; e < p.ne; e++) p.ngram += reg.gptr[e + 1] > reg.gptr[e];
+        std::vector<int> ei2, ej2, gptr2(1, 0), grow2;
+        std::vector<double> gval2;
+        for (int e : order) {
+            ei2.push_back(ei[e]); ej2.push_back(ej[e]);
+            for (int k = reg.gptr[e]; k < reg.gptr[e + 1]; k++) { grow2.push_back(reg.grow[k]); gval2.push_back(reg.gval[k]); }
+            gptr2.push_back((int)grow2.size());
+        }
+        ei.swap(ei2); ej.swap(ej2); reg.gptr.swap(gptr2); reg.grow.swap(grow2); reg.gval.swap(gval2);
+        if (p.ngram > 64) p.static_rows = 0;
+    }
 
     auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
     int rc = HMPC_OK;

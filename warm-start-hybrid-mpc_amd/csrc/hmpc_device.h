@@ -31,6 +31,7 @@ struct DevProb {
     const double *ccv;                         // columns of the stage rows padded to HMPC_KC_STRIDE (value, local row)
     const int *cci;
     int kcol;                                  // longest column of the stage rows
+    int ngram;                                 // entries of C' D C with a nonempty term list (numbered first)
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT

@@ -127,6 +127,17 @@ DEV double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// Reciprocal to ~1 ulp: v_rcp_f64 (measured on MI355X: 4.5e-8 relative) and two Newton steps (2e-15, then
+// rounding level).  The row loops divide by slacks and multipliers a dozen times per row and iteration;
+// the IEEE division sequence is three times as long and its last-bit guarantees buy nothing there.
+DEV double frcp(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+
 // LDS pointers carry their address space so that every access is a ds_read / ds_write (a generic
 // pointer would compile to flat_load: slower, and it ties up both memory counters).
 typedef __attribute__((address_space(3))) double ldsd;
@@ -621,54 +632,128 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Same factorisation for the compile-time shapes, with the stage matrix in registers of wave 0:
-// lane c < nz owns column c of M.  A pivot step broadcasts the pivot column with v_readlane
-// (wave-uniform SGPR values) and every lane updates its own column: no LDS traffic and no barrier
-// inside the elimination.  Two barriers per stage: after the Gram / P[A B] phase (all waves) and
-// after the write-back.
+// Same factorisation for the compile-time shapes, entirely in wave 0 and without a barrier inside the
+// stage loop.  Per stage:
+//   * Gram: lane e < ngram owns one entry (i, j) of C' D C with a nonempty term list (the host numbers
+//     those first; at most 64) and sums its terms from fenced batches of LDS loads; entries without
+//     terms are constant (M = P there) and written once per factorisation;
+//   * W = [A B]' P_{t+1} [A B] in registers: lanes c < nx hold column c of P_{t+1} from the previous
+//     stage's elimination, lane c computes y = P_{t+1} [A B](:, c) and then column c of W, every
+//     operand of another lane through v_readlane (wave-uniform SGPRs) -- no LDS round trip between
+//     two stages;
+//   * lane c < nz then owns column c of M = P + C' D C + W.  A pivot step broadcasts the pivot column
+//     with v_readlane and every lane updates its own column.  Fixed binaries are prescribed (identity
+//     row / column): their pivot steps are arithmetic no-ops, so the elimination needs no branch.
 // ---------------------------------------------------------------------------------------------
 template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
-    constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
+    constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU), KG = D::kKC, GH = KG / 2;
     const int T = p.T;
     FSTAMP_DECL;
     LANE_OPAQUE(lane);
     if (lane == 0) S.flag[0] = 0;
-    for (int e = lane; e < NX * NX; e += D::kNT) {
-        const int i = e / NX, j = e - i * NX;
-        if (i >= j) S.Pr[T * NXS + sym(i, j)] = S.PT[e];
-    }
-    __syncthreads();
-    for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Pn = S.Pr + (t + 1) * NXS;
-        const ldsi *fx = S.fix + t * NUB;
-        // phase 1 (LDS, all waves): M = P + C' D C by Gram lists ; PA = Pn [A B]
-        for (int e = lane; e < NE; e += D::kNT) {
-            const int i = S.ei[e], j = S.ej[e];
-            const double a = S.P[i * NZ + j] + gram_entry<D>(p, S, t, e, i, j);
+    if (D::kNW == 1 || lane < WAVE) {
+        const int ng = p.ngram;
+        const bool has = lane < ng;
+        const int ge = has ? lane : 0;
+        const int gi = S.ei[ge], gj = S.ej[ge];
+        const int gp0 = S.L0.gptr[ge], glen = has ? S.L0.gptr[ge + 1] - gp0 : 0;
+        const double pij = S.P[gi * NZ + gj];
+        ldsd *TG = S.Mm + NZ * NZ; // dense terminal block of the last stage (when active)
+        for (int q = ng + lane; q < NE; q += WAVE) {
+            const int i = S.ei[q], j = S.ej[q];
+            const double a = S.P[i * NZ + j];
             S.Mm[i * NZ + j] = a;
             S.Mm[j * NZ + i] = a;
         }
-        for (int e = lane; e < NX * NZ; e += D::kNT) {
-            const int i = e / NZ, j = e - i * NZ;
-            double a = 0;
-#pragma unroll
-            for (int l = 0; l < NX; l++) a += Pn[sym(i, l)] * S.AB[l * NZ + j];
-            S.PA[e] = a;
+        if (S.term_on) {
+            for (int q = lane; q < NE; q += WAVE) {
+                const int i = S.ei[q], j = S.ej[q];
+                const ldsd *Dt = S.e + p.Toff;
+                double a0 = 0, a1 = 0;
+                int k = 0;
+                for (; k + 2 <= p.nT; k += 2) {
+                    a0 += p.Ct[(size_t)k * NZ + i] * p.Ct[(size_t)k * NZ + j] * Dt[k];
+                    a1 += p.Ct[(size_t)(k + 1) * NZ + i] * p.Ct[(size_t)(k + 1) * NZ + j] * Dt[k + 1];
+                }
+                if (k < p.nT) a0 += p.Ct[(size_t)k * NZ + i] * p.Ct[(size_t)k * NZ + j] * Dt[k];
+                TG[i * NZ + j] = a0 + a1;
+                TG[j * NZ + i] = a0 + a1;
+            }
         }
-        __syncthreads();
-        FSTAMP(0);
-        if (D::kNW == 1 || lane < WAVE) { // phase 2 (registers, wave 0): assemble the column, prescribe, eliminate
+        double ABc[NX], pn[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) ABc[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; i++) pn[i] = lane < NX ? S.PT[i * NX + lane] : 0.0;
+        if (lane < NX) {
+#pragma unroll
+            for (int i = 0; i < NX; i++)
+                if (i >= lane) S.Pr[T * NXS + sym(i, lane)] = pn[i];
+        }
+        int bad = 0;
+        for (int t = T - 1; t >= 0; t--) {
+            const ldsi *fx = S.fix + t * NUB;
             ldsd *Lm = S.Lm + t * LMS;
+            int fxv[NUB];
+#pragma unroll
+            for (int b = 0; b < NUB; b++) fxv[b] = fx[b];
+            // (1) this lane's Gram entry
+            double g0 = pij, g1 = 0.0;
+            {
+                const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
+#pragma unroll
+                for (int hb = 0; hb < KG; hb += GH) {
+                    int idx[GH];
+                    double gv[GH], dv[GH];
+#pragma unroll
+                    for (int q = 0; q < GH; q++) {
+                        const int qq = gp0 + (hb + q < glen ? hb + q : 0);
+                        idx[q] = S.L0.grow[qq];
+                        gv[q] = S.L0.gval[qq];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < GH; q++) dv[q] = Dt[idx[q]];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < GH; q++) {
+                        const double term = hb + q < glen ? gv[q] * dv[q] : 0.0;
+                        if (q & 1) g1 += term;
+                        else g0 += term;
+                    }
+                }
+            }
+            if (has) {
+                S.Mm[gi * NZ + gj] = g0 + g1;
+                S.Mm[gj * NZ + gi] = g0 + g1;
+            }
+            // (2) column `lane` of W = [A B]' P_{t+1} [A B]
+            double y[NX];
+#pragma unroll
+            for (int i = 0; i < NX; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; l++) a += bcast(pn[l < i ? l : i], l < i ? i : l) * ABc[l]; // P_{t+1}(i, l), symmetric
+                y[i] = a;
+            }
             double col[NZ];
+#pragma unroll
+            for (int i = 0; i < NZ; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int l = 0; l < NX; l++) a += bcast(ABc[l], i) * y[l];
+                col[i] = a;
+            }
+            FSTAMP(0);
+            // (3) + P + C' D C (this wave wrote it: LDS operations of one wave complete in order)
             if (lane < NZ) {
 #pragma unroll
-                for (int i = 0; i < NZ; i++) {
-                    double a = S.Mm[i * NZ + lane];
+                for (int i = 0; i < NZ; i++) col[i] += S.Mm[i * NZ + lane];
+                if (S.term_on && t == T - 1) {
 #pragma unroll
-                    for (int l = 0; l < NX; l++) a += S.AB[l * NZ + i] * S.PA[l * NZ + lane];
-                    col[i] = a;
+                    for (int i = 0; i < NZ; i++) col[i] += TG[i * NZ + lane];
                 }
             } else {
 #pragma unroll
@@ -677,7 +762,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             FSTAMP(1);
             int nfixed = 0;
 #pragma unroll
-            for (int b = 0; b < NUB; b++) nfixed += fx[b] >= 0;
+            for (int b = 0; b < NUB; b++) nfixed += fxv[b] >= 0;
             if (nfixed) {
                 // columns of binaries fixed to one (for the constant direction), before prescribing
                 double mbv[NZ];
@@ -685,7 +770,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 for (int i = 0; i < NZ; i++) mbv[i] = 0.0;
 #pragma unroll
                 for (int b = 0; b < NUB; b++)
-                    if (fx[b] == 1) {
+                    if (fxv[b] == 1) {
 #pragma unroll
                         for (int i = 0; i < NZ; i++) mbv[i] += bcast(col[i], NX + NUC + b);
                     }
@@ -695,7 +780,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 }
 #pragma unroll
                 for (int b = 0; b < NUB; b++)
-                    if (fx[b] >= 0) {
+                    if (fxv[b] >= 0) {
                         const int cb = NX + NUC + b;
 #pragma unroll
                         for (int i = 0; i < NZ; i++)
@@ -705,29 +790,22 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 S.g[t * NZ + lane] = 0.0;
             }
             FSTAMP(2);
-            int bad = 0;
             // The multiplier of row i at pivot j is M(i, pj) / d; by symmetry lane i holds it as
             // col[pj] / d, so every lane keeps the multipliers of its own row and stores them once.
             double myrow[NU], dinv[NU];
 #pragma unroll
             for (int j = 0; j < NU; j++) {
-                myrow[j] = 0.0;
-                dinv[j] = 1.0;
-                if (j >= NUC && fx[j - NUC] >= 0) continue; // decoupled unit pivot: the solves skip it as well
                 const int pj = NX + j;
-                const double d = bcast(col[pj], pj);
+                const double d = bcast(col[pj], pj); // 1 at a prescribed pivot: the step below changes nothing
                 if (!(d > 0.0)) bad = 1;
                 double rinv = __builtin_amdgcn_rcp(d);
                 rinv = rinv * (2.0 - d * rinv);
                 dinv[j] = rinv;
-                const double cpj = col[pj];
-                if (lane < NX || lane > pj) myrow[j] = cpj * rinv;
+                const double cr = col[pj] * rinv;
+                myrow[j] = (lane < NX || lane > pj) ? cr : 0.0;
 #pragma unroll
                 for (int i = 0; i < NZ; i++) {
-                    if (i < NX || i > pj) { // rows still to be reduced
-                        const double m = bcast(col[i], pj) * rinv;
-                        col[i] -= m * cpj;
-                    }
+                    if (i < NX || i > pj) col[i] -= bcast(col[i], pj) * cr; // rows still to be reduced
                 }
             }
             if (lane < NZ) { // rows of the states: NU entries; row i of the inputs: its i entries (zeros at skipped pivots)
@@ -743,16 +821,18 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 S.dinv[t * NU + lane] = dv;
             }
             FSTAMP(3);
+#pragma unroll
+            for (int i = 0; i < NX; i++) pn[i] = col[i];
             if (lane < NX) {
 #pragma unroll
                 for (int i = 0; i < NX; i++)
                     if (i >= lane) S.Pr[t * NXS + sym(i, lane)] = col[i];
             }
-            if (lane == 0 && bad) S.flag[0] = 1;
+            FSTAMP(4);
         }
-        __syncthreads();
-        FSTAMP(4);
+        if (lane == 0 && bad) S.flag[0] = 1;
     }
+    __syncthreads();
     return S.flag[0] ? -1 : 0;
 }
 
@@ -1297,7 +1377,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         __syncthreads(); // every thread is done reading z from S.e
         ROWS_BEGIN(k, rw)
             const double zr = R.z(k, rw.e); // zero on inactive rows
-            const double d = zr != 0.0 ? zr / R.s(k, rw.e) : 0.0;
+            const double d = zr != 0.0 ? zr * frcp(R.s(k, rw.e)) : 0.0;
             R.D(k, rw.e) = d; // the slot holds D from here to the update of this iteration
             S.e[rw.e] = d;    // S.e <- D for the Gram phase of the factorisation
         ROWS_END
@@ -1346,7 +1426,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     const double sr = R.s(k, rw.e), zr = d * sr;
                     const double rc = sr - rm.h(p, S, k, rw) * tau + rm.dot(p, S, k, rw, S.w); // row residual
                     const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
-                    v = d * (-lin * rc + dsr / zr);
+                    v = dsr * frcp(sr) - lin * (d * rc); // d (-lin rc + dsr / z) with z = d s
                 }
                 S.e[rw.e] = v;
             ROWS_END
@@ -1427,8 +1507,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         const double sr = R.s(k, rw.e), zr = d * sr, hh = rm.h(p, S, k, rw);
                         const double rc = sr - hh * tau + rm.dot(p, S, k, rw, S.w);
                         const double dsr = sr * zr + R.prod(k, rw.e) - sigma * mu;
-                        const double a = -lin * rc + dsr / zr + dtau * hh + S.e[rw.e] * sr / zr - rm.dot(p, S, k, rw, S.w2);
-                        v = d * a;
+                        // d (-lin rc + dsr / z + dtau h + dz s / z - C w2) with z = d s
+                        const double a = -lin * rc + dtau * hh - rm.dot(p, S, k, rw, S.w2);
+                        v = d * a + (dsr * frcp(sr) + S.e[rw.e]);
                     }
                     S.e[rw.e] = v;
                 ROWS_END
@@ -1452,9 +1533,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 if (R.D(k, rw.e) != 0.0) {
                     const double dz = R.dz(k, rw.e), sr = R.s(k, rw.e), zr = R.D(k, rw.e) * sr;
                     const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
-                    const double ds = -(dsr + sr * dz) / zr;
-                    if (dz < 0) amax = fmin(amax, -zr / dz);
-                    if (ds < 0) amax = fmin(amax, -sr / ds);
+                    const double ds = -(dsr + sr * dz) * frcp(zr);
+                    if (dz < 0) amax = fmin(amax, -zr * frcp(dz));
+                    if (ds < 0) amax = fmin(amax, -sr * frcp(ds));
                     if (pass == 0) R.prod(k, rw.e) = ds * dz;
                     else R.prod(k, rw.e) = ds; // the affine product is consumed: keep the slack step here (also for an undo)
                 }
@@ -1724,18 +1805,20 @@ struct hmpc_kernel_choice {
     int waves;
     int kc; // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
 };
-// Waves per node: measured on MI355X (cart-pole N=20) one wave per node gives the best throughput
-// once every CU holds its three nodes (221 k QP/s at 4096 nodes vs 184 k / 138 k with 2 / 4 waves),
-// while small frontiers finish sooner with the parallel phases spread over more waves (77 nodes:
-// 4.06 / 3.12 / 2.80 ms).  HMPC_WAVES overrides.
+// Waves per node, measured on MI355X (cart-pole N=20, ms per batch with 1 / 2 / 4 waves):
+//   8 nodes 1.81 / 1.50 / 1.41    77: 2.78 / 2.26 / 2.09    256: 2.88 / 2.47 / 2.30
+//   512: 2.95 / 2.67 / 3.76       1024: 3.69 / 6.81 / 6.92  2048: 7.46 / 11.1 / 12.5
+// A CU holds 4 waves of this kernel (one per SIMD, 512 registers each): a frontier that fills every
+// SIMD with one node per wave is fastest with one wave per node; smaller frontiers finish sooner with
+// the row-parallel phases spread over the otherwise idle SIMDs.  HMPC_WAVES overrides.
 static int hmpc_waves_for(int B, int resident_nodes)
 {
     if (const char *e = getenv("HMPC_WAVES")) {
         const int nw = atoi(e);
         if (nw == 1 || nw == 2 || nw == 4) return nw;
     }
-    if (B <= resident_nodes / 3) return 4;
-    if (B <= 2 * resident_nodes) return 2;
+    if (B <= resident_nodes / 4) return 4;
+    if (B <= resident_nodes / 2) return 2;
     return 1;
 }
 // Slots the static row map needs for this problem with nw waves per node (see RowMapS).
