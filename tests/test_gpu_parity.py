@@ -30,7 +30,7 @@ def _traj_tol(fix):
     return np.where(frac >= 0.9, RTOL_DEGENERATE, RTOL)
 
 
-def _compare(ctrl, a, b, T, fix=None):
+def _compare(ctrl, a, b, T, fix=None, rtol_traj=None):
     assert np.array_equal(a['status'], b['status']), np.flatnonzero(a['status'] != b['status'])
     assert np.all(a['status'] <= 1)
     fin = a['status'] == 0
@@ -39,7 +39,7 @@ def _compare(ctrl, a, b, T, fix=None):
     nx = ctrl.mld.nx
     xa, xb = a['primal'][fin][:, :(T + 1) * nx], b['primal'][fin][:, :(T + 1) * nx]
     scale = np.maximum(1e-2, np.max(np.abs(xb), axis=1, keepdims=True))
-    tol = RTOL if fix is None else _traj_tol(fix)[fin][:, None]
+    tol = rtol_traj if rtol_traj is not None else RTOL if fix is None else _traj_tol(fix)[fin][:, None]
     assert np.all(np.abs(xa - xb) / scale < tol), np.max(np.abs(xa - xb) / scale)
     inf = a['status'] == 1
     assert np.all(np.isinf(a['obj'][inf])) and np.all(np.isnan(a['primal'][inf]))
@@ -208,11 +208,57 @@ def test_other_problem_shapes_and_size_limit():
     fix = random_prefix_frontier(8, 3, 128, p_one=0.3)
     fix[0, :] = -1
     _compare(ctrl, hip.solve_batch(x0, fix), orc.solve_batch(x0, fix), 8, fix)
-    # BASELINE.json configs[4] (nx=20, nu=14, N=30) does not fit one CU's LDS in this kernel: loud error
+
+
+def test_streaming_kernel_baseline_config4():
+    # BASELINE.json configs[4] (random MLD nx=20, nu=6+8, N=30; rows as in SURVEY 8(d) C4): lists and
+    # Riccati factor do not fit one CU's LDS, the generic kernel's streaming form keeps them in global memory
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
     mld, objective, x0 = random_mld()
-    big = HybridModelPredictiveController(mld, 30, objective, None, backend=_NoBackend())
+    T = 30
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    hip, orc = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=8)
+    # frontier: prefixes of a dive to a feasible leaf (binaries of stage t from the sign of c_j'x_t of the
+    # current relaxation), every other one with one flipped binary -- random prefixes are all infeasible here
+    nub, nx = 8, 20
+    Cj = np.array([mld.F[52 + 4 * j] for j in range(nub)])
+    leaf = np.full((1, T * nub), -1, np.int8)
+    for t in range(T):
+        r = orc.solve_batch(x0, leaf)
+        assert r['status'][0] == 0
+        leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+    rng = np.random.default_rng(0)
+    fix = np.full((48, T * nub), -1, np.int8)
+    for k in range(1, 48):
+        d = int(rng.integers(1, T * nub + 1))
+        fix[k, :d] = leaf[0, :d]
+        if k % 2 == 0:
+            j = int(rng.integers(0, d))
+            fix[k, j] = 1 - fix[k, j]
+    a, b = hip.solve_batch(x0, fix), orc.solve_batch(x0, fix)
+    assert hip.launch_info()[1] > 100 * 1024          # the streaming carve: vectors only, still most of a CU
+    # this generator leaves the binaries out of the cost (R = [I 0], as the reference does): the QP is only
+    # positive SEMIdefinite in the inputs, the minimiser is not isolated in those directions and the state
+    # trajectory is determined to ~1e-4 by a 1e-8 residual; objectives and certificates agree to 2e-6
+    _compare(ctrl, a, b, T, fix, rtol_traj=1e-4)
+    assert (a['status'] == 0).sum() >= 1 and (a['status'] == 1).sum() >= 1
+    # a problem whose vectors alone exceed a CU's LDS is still refused loudly
+    huge = HybridModelPredictiveController(mld, 60, objective, None, backend=_NoBackend())
     with pytest.raises(RuntimeError, match='LDS'):
-        HipBatchedQP(big.problem_data())
+        HipBatchedQP(huge.problem_data())
+
+
+def test_streaming_kernel_forced_on_cart_pole(monkeypatch):
+    # the same streaming code path on the reference's system, against the oracle
+    monkeypatch.setenv('HMPC_FORCE_BIG', '1')
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    monkeypatch.delenv('HMPC_FORCE_BIG')
+    orc = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
+    fix = random_prefix_frontier(20, 4, 96, p_one=0.2, seed0=7000)
+    fix[0, :] = -1
+    _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix)
 
 
 def test_lockstep_closed_loops_on_gpu():

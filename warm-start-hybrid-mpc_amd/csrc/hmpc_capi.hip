@@ -302,7 +302,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     for (int c = 0; c < 3; c++) {
         hmpc_cfg &cf = h->cfg[c];
         cf.k = hmpc_pick_kernel(p, 1 << c);
-        cf.lds = hmpc_lds_bytes(p, cf.k.kc);
+        cf.lds = hmpc_lds_bytes(p, cf.k.kc, cf.k.big);
         if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
             char msg[256];
             snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max);
@@ -320,6 +320,16 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         if (cf.max_grid > h->max_grid) h->max_grid = cf.max_grid;
     }
     h->lds = h->cfg[0].lds;
+    p.fac_ws = nullptr;
+    p.fac_stride = 0;
+    if (h->cfg[0].k.big || h->cfg[1].k.big || h->cfg[2].k.big) {
+        p.fac_stride = p.T * (p.nx * p.nu + p.nu * (p.nu - 1) / 2) + (p.T + 1) * (p.nx * (p.nx + 1) / 2);
+        if (hipMalloc((void **)&p.fac_ws, (size_t)h->max_grid * p.fac_stride * sizeof(double)) != hipSuccess) {
+            hmpc_destroy(h);
+            return fail(HMPC_EDEVICE, "cannot allocate the factor workspace");
+        }
+        h->allocs.push_back(p.fac_ws);
+    }
     if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 4 * p.Mpad * sizeof(double)) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");

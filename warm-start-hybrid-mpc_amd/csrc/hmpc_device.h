@@ -32,6 +32,8 @@ struct DevProb {
     const int *cci;
     int kcol;                                  // longest column of the stage rows
     int ngram;                                 // entries of C' D C with a nonempty term list (numbered first)
+    double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
+    int fac_stride;                            //   doubles per workgroup
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
@@ -48,8 +50,9 @@ struct DevOut {
 };
 
 // LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).  kc: entries per padded column of
-// the kernel's compile-time shape (Dims::kKC), 0 for the generic kernel.
-static inline size_t hmpc_lds_bytes(const DevProb &p, int kc)
+// the kernel's compile-time shape (Dims::kKC), 0 for the generic kernel; big: the generic kernel's streaming
+// form (lists and Riccati factor in global memory).
+static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
 {
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
     size_t d = 0, i = 0, b = 0;
@@ -57,16 +60,20 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc)
     const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
     d += dir;                                                             // w lam nuf
     d += M;                                                               // e (row vector: z / D / D.*rhs / dz in turn)
-    d += T * lms + T * nu + (T + 1) * nxs;                                // Lm dinv Pr
+    d += T * nu + (big ? 0 : T * lms + (T + 1) * nxs);                    // dinv ; Lm Pr (global slab if big)
     d += n + 2 * T * nx + n + (T + 1) * nx;                               // rd rdyn edyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
     d += nx + nz + 40;                                                    // q mv red
     d += nx;                                                              // x0
     d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
     i += 2 + T * nub + 2 * (size_t)p.ne;                                  // flag fix ei ej
-    i += (p.ne + 1) + p.nng0;                                             // gptr0 grow0
-    d += p.mreg + p.nng0;                                                 // h0 gval0
-    if (kc > 0) {
+    if (!big) {
+        i += (p.ne + 1) + p.nng0;                                         // gptr0 grow0
+        d += p.mreg + p.nng0;                                             // h0 gval0
+    }
+    if (big) {
+        // the lists stay in global memory
+    } else if (kc > 0) {
         d += nz * (size_t)kc;                                             // padded column values
         b += (nz * (size_t)kc + 3) / 4 * 4;                               // padded column rows (bytes)
     } else {

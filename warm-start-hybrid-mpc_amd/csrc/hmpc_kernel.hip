@@ -151,6 +151,7 @@ struct Lists {
     DP rval, cval, gval, h;
 };
 typedef Lists<const ldsi *, const ldsd *> ListsL;
+typedef Lists<const int *, const double *> ListsG;
 
 struct Lds {
     ldsd *w, *lam, *nuf;
@@ -166,6 +167,8 @@ struct Lds {
     ldsd *AB, *P, *PT; // [A B] (nx x nz), scaled cost Hessians
     ldsi *ei, *ej;     // lower-triangle entry -> (i, j)
     ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
+    ListsG G0;         // the same lists left in global memory, and the Riccati factor in a global slab:
+    double *LmG, *PrG; //   the streaming variant for problems whose factor does not fit in LDS (Dims::kBig)
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
@@ -177,6 +180,9 @@ template <int NX_, int NU_, int NUB_, int NW_>
 struct Dims {
     static constexpr int kNX = NX_, kNU = NU_, kNUB = NUB_;
     static constexpr int kNW = NW_, kNT = NW_ * 64; // waves / threads per node (workgroup)
+    // NX_ < 0: the generic kernel with the stage lists and the Riccati factor (multipliers, cost-to-go) in
+    // global memory (L2 resident) instead of LDS -- for problems beyond 160 KiB of LDS per node
+    static constexpr bool kBig = NX_ < 0;
     // entries per padded column of the stage rows (compile-time shapes): the cart-pole systems have at
     // most 14 (nu = 7) and 8 (nu = 4); a problem of the same shape with fuller columns takes the generic kernel
     static constexpr int kKC = NX_ > 0 ? (NU_ == 7 ? 14 : 8) : 0;
@@ -187,6 +193,22 @@ struct Dims {
     static DEV int nz(const DevProb &p) { return NX_ > 0 ? NX_ + NU_ : p.nz; }
     static DEV int ne(const DevProb &p) { return NX_ > 0 ? (NX_ + NU_) * (NX_ + NU_ + 1) / 2 : p.ne; }
 };
+
+template <class D> DEV decltype(auto) stage_lists(const Lds &S)
+{
+    if constexpr (D::kBig) return (S.G0);
+    else return (S.L0);
+}
+template <class D> DEV auto fac_lm(const Lds &S)
+{
+    if constexpr (D::kBig) return S.LmG;
+    else return S.Lm;
+}
+template <class D> DEV auto fac_pr(const Lds &S)
+{
+    if constexpr (D::kBig) return S.PrG;
+    else return S.Pr;
+}
 
 // Per-row values that only the owning lane touches: slack s, multiplier z, combined step dz, affine
 // product / slack step prod.  The barrier weight D = z/s (0 on inactive rows) SHARES the storage of z:
@@ -295,7 +317,7 @@ template <class L> DEV double gram(const L &st, int e, const ldsd *D)
 // C_t row / column products.  `base` is a row-indexed LDS vector (z, e, ...); `v` a stage vector.
 template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, const ldsd *v)
 {
-    if (lr < p.mreg) return row_dot(S.L0, lr, v);
+    if (lr < p.mreg) return row_dot(stage_lists<D>(S), lr, v);
     const int nz = D::nz(p);
     const double *c = p.Ct + (size_t)(lr - p.mreg) * nz; // dense terminal row
     double a = 0;
@@ -334,7 +356,7 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
         }
         a = a0 + a1;
     } else {
-        a = col_dot(S.L0, j, base + t * p.mreg);
+        a = col_dot(stage_lists<D>(S), j, base + t * p.mreg);
     }
     if (S.term_on && t == p.T - 1) {
         const int nz = D::nz(p);
@@ -350,7 +372,7 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
     }
     return a;
 }
-DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? S.L0.h[lr] : p.ht[lr - p.mreg]; }
+template <class D> DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? stage_lists<D>(S).h[lr] : p.ht[lr - p.mreg]; }
 // ---------------------------------------------------------------------------------------------
 // Row maps: which rows a lane owns and how it evaluates them.
 //
@@ -382,7 +404,7 @@ template <class D> struct RowMapL {
         return true;
     }
     DEV bool active(const DevProb &p, const Lds &S, int, const Ref &rw) const { return row_active<D>(p, S.fix, rw.t, rw.lr, S.term_on); }
-    DEV double h(const DevProb &p, const Lds &S, int, const Ref &rw) const { return hrow(p, S, rw.lr); }
+    DEV double h(const DevProb &p, const Lds &S, int, const Ref &rw) const { return hrow<D>(p, S, rw.lr); }
     DEV double dot(const DevProb &p, const Lds &S, int, const Ref &rw, const ldsd *vec) const
     {
         return crow_dot<D>(p, S, rw.lr, vec + rw.t * D::nz(p));
@@ -500,7 +522,7 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
 // (C' D C)(i, j) of stage t: Gram lists of the stage rows, plus the dense terminal block if active
 template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, int e, int i, int j)
 {
-    double a = gram(S.L0, e, S.e + t * p.mreg); // S.e holds D during the factorisation
+    double a = gram(stage_lists<D>(S), e, S.e + t * p.mreg); // S.e holds D during the factorisation
     if (S.term_on && t == p.T - 1) {
         const int nz = D::nz(p);
         const ldsd *Dt = S.e + p.Toff;
@@ -544,14 +566,14 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     for (int e = lane; e < nx * nx; e += D::kNT) {
         const int i = e / nx, j = e - i * nx;
-        if (i >= j) S.Pr[T * nxs + sym(i, j)] = S.PT[e];
+        if (i >= j) fac_pr<D>(S)[T * nxs + sym(i, j)] = S.PT[e];
     }
     __syncthreads();
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Pn = S.Pr + (t + 1) * nxs;
+        const auto Pn = fac_pr<D>(S) + (t + 1) * nxs;
         const ldsi *fx = S.fix + t * nub;
-        ldsd *Lm = S.Lm + t * lms;
+        const auto Lm = fac_lm<D>(S) + t * lms;
         int nfixed = 0;
         for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
         // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
@@ -624,7 +646,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         }
         for (int e = lane; e < nx * nx; e += D::kNT) {
             const int i = e / nx, j = e - i * nx;
-            if (i >= j) S.Pr[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
+            if (i >= j) fac_pr<D>(S)[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
         }
         __syncthreads();
     }
@@ -862,11 +884,11 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     __syncthreads();
     // backward sweep
     for (int t = T - 1; t >= 0; t--) {
-        const ldsd *Lm = S.Lm + t * lms;
+        const auto Lm = fac_lm<D>(S) + t * lms;
         const ldsi *fx = S.fix + t * nub;
         const ldsd *qv = S.pv + (t + 1) * nx;
         if (csrc) {
-            const ldsd *Pn = S.Pr + (t + 1) * nxs;
+            const auto Pn = fac_pr<D>(S) + (t + 1) * nxs;
             for (int i = lane; i < nx; i += D::kNT) {
                 double a = S.pv[(t + 1) * nx + i];
                 for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * cs * csrc[t * nx + l];
@@ -905,7 +927,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     for (int i = lane; i < nx; i += D::kNT) dw[i] = usex0 ? S.x0[i] : 0.0;
     __syncthreads();
     for (int t = 0; t < T; t++) {
-        const ldsd *Lm = S.Lm + t * lms;
+        const auto Lm = fac_lm<D>(S) + t * lms;
         const ldsi *fx = S.fix + t * nub;
         const ldsd *x = dw + t * nz;
         // c = L_x' x + dinv .* y ; then back substitution with L_u', u = -(result)
@@ -938,7 +960,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     for (int o = lane; o < (T + 1) * nx; o += D::kNT) {
         const int t = o / nx, i = o - t * nx;
         double a = S.pv[o];
-        for (int l = 0; l < nx; l++) a += S.Pr[t * nxs + sym(i, l)] * dw[t * nz + l];
+        for (int l = 0; l < nx; l++) a += fac_pr<D>(S)[t * nxs + sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
     {
@@ -1625,7 +1647,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
             const double sc = lr < p.nc ? p.reg.scale[lr] : p.sct[lr - p.mreg];
             const double v = S.e[r] * scale * sc;
             if (dual) dual[o_mu + t * p.nc + (lr < p.nc ? lr : p.nc + (lr - p.mreg))] = v;
-            farkas -= (hrow(p, S, lr) / sc) * v;
+            farkas -= (hrow<D>(p, S, lr) / sc) * v;
         }
     }
     for (int o = lane; o < T * nub; o += D::kNT) {
@@ -1691,7 +1713,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef Dims<NX_, NU_, NUB_, NW> D;
     constexpr int RS = KF + KB + KT;
-    static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernel the lists");
+    static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernels the lists");
     typedef typename std::conditional<(NX_ > 0), RowMapS<D, KF, KB, KT>, RowMapL<D>>::type RM;
     const int lane = threadIdx.x; // thread of the workgroup; wave 0 (lane < 64) runs the recursions
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M, n = T * nz + nx, ne = D::ne(p);
@@ -1703,7 +1725,8 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.w = take(n); S.lam = take((T + 1) * nx); S.nuf = take(T * nub);
         S.e = take(M);
         const int nxs = nx * (nx + 1) / 2;
-        S.Lm = take(T * LM_STAGE(nx, nu)); S.dinv = take(T * nu); S.Pr = take((T + 1) * nxs);
+        S.Lm = take(D::kBig ? 0 : T * LM_STAGE(nx, nu)); S.dinv = take(T * nu); S.Pr = take(D::kBig ? 0 : (T + 1) * nxs);
+        S.LmG = p.fac_ws + (size_t)blockIdx.x * p.fac_stride; S.PrG = S.LmG + (size_t)T * LM_STAGE(nx, nu);
         S.rd = take(n); S.rdyn = take(T * nx); S.edyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         // the second direction is dead while a factorisation runs: its storage doubles as the
@@ -1717,15 +1740,17 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         // lists of the regular stage: the generic kernel stages rows, columns and Gram lists; the
         // compile-time shapes padded columns and Gram lists (their rows live in registers)
         constexpr int KC = D::kKC;
-        ldsd *h0 = take(p.mreg), *rval0 = take(KC ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : p.nnz0), *gval0 = take(p.nng0);
+        constexpr bool NL = KC > 0 || D::kBig; // no row / column lists in LDS
+        ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
+        ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
         S.flag = takei(2);
         S.fix = takei(T * nub);
         S.ei = takei(ne); S.ej = takei(ne);
-        ldsi *rptr0 = takei(KC ? 0 : p.mreg + 1), *rcol0 = takei(KC ? 0 : p.nnz0), *cptr0 = takei(KC ? 0 : nz + 1);
-        ldsi *crow0 = takei(KC ? 0 : p.nnz0);
-        ldsi *gptr0 = takei(ne + 1), *grow0 = takei(p.nng0);
+        ldsi *rptr0 = takei(NL ? 0 : p.mreg + 1), *rcol0 = takei(NL ? 0 : p.nnz0), *cptr0 = takei(NL ? 0 : nz + 1);
+        ldsi *crow0 = takei(NL ? 0 : p.nnz0);
+        ldsi *gptr0 = takei(D::kBig ? 0 : ne + 1), *grow0 = takei(D::kBig ? 0 : p.nng0);
         ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
@@ -1735,8 +1760,11 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
         for (int i = lane; i < nz * nz; i += D::kNT) S.P[i] = p.P[i];
         for (int i = lane; i < nx * nx; i += D::kNT) S.PT[i] = p.PT[i];
-        for (int i = lane; i < p.mreg; i += D::kNT) h0[i] = g0.h[i];
-        if constexpr (KC > 0) {
+        if constexpr (!D::kBig)
+            for (int i = lane; i < p.mreg; i += D::kNT) h0[i] = g0.h[i];
+        if constexpr (D::kBig) {
+            // nothing staged: the lists are walked in global memory (read-only, L2 resident)
+        } else if constexpr (KC > 0) {
             for (int i = lane; i < nz * KC; i += D::kNT) {
                 const int j = i / KC, qq = i - j * KC;
                 cval0[i] = p.ccv[j * HMPC_KC_STRIDE + qq];
@@ -1747,10 +1775,13 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
             for (int i = lane; i < p.mreg + 1; i += D::kNT) rptr0[i] = g0.rptr[i];
             for (int i = lane; i < nz + 1; i += D::kNT) cptr0[i] = g0.cptr[i];
         }
-        for (int i = lane; i < p.nng0; i += D::kNT) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
-        for (int i = lane; i < ne + 1; i += D::kNT) gptr0[i] = g0.gptr[i];
+        if constexpr (!D::kBig) {
+            for (int i = lane; i < p.nng0; i += D::kNT) { gval0[i] = g0.gval[i]; grow0[i] = g0.grow[i]; }
+            for (int i = lane; i < ne + 1; i += D::kNT) gptr0[i] = g0.gptr[i];
+        }
         for (int i = lane; i < ne; i += D::kNT) { S.ei[i] = p.ei[i]; S.ej[i] = p.ej[i]; }
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
+        S.G0 = ListsG{g0.rptr, g0.rcol, g0.cptr, g0.crow, g0.gptr, g0.grow, g0.rval, g0.cval, g0.gval, g0.h};
         S.ccv = cval0;
         S.cci = cci0;
         S.term_on = 0;
@@ -1803,7 +1834,8 @@ typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *
 struct hmpc_kernel_choice {
     hmpc_kernel_t fn;
     int waves;
-    int kc; // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
+    int kc;  // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
+    int big; // generic kernel with lists and factor in global memory (Dims::kBig)
 };
 // Waves per node, measured on MI355X (cart-pole N=20, ms per batch with 1 / 2 / 4 waves):
 //   8 nodes 1.81 / 1.50 / 1.41    77: 2.78 / 2.26 / 2.09    256: 2.88 / 2.47 / 2.30
@@ -1834,10 +1866,10 @@ static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &k
 }
 #define HMPC_TRY(NX, NU, NUB, F, Bn, Tn, NWv) \
     if (kf <= F && kb <= Bn && kt <= Tn && p.kcol <= Dims<NX, NU, NUB, NWv>::kKC)       \
-        return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, NWv, Dims<NX, NU, NUB, NWv>::kKC};
+        return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, NWv, Dims<NX, NU, NUB, NWv>::kKC, 0};
 static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
 {
-    const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr;
+    const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr || getenv("HMPC_FORCE_BIG") != nullptr;
     int kf = 0, kb = 0, kt = 0;
     if (!generic && p.nx == 4 && p.nu == 7 && p.nub == 4) {
         // smallest instantiation that holds the rows; fewer waves than asked for never fit more rows
@@ -1855,9 +1887,15 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
             if (w == 4) { HMPC_TRY(4, 4, 2, 4, 1, 1, 4) }
         }
     }
-    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, 1, 0};
-    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, 2, 0};
-    return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, 4, 0};
+    // generic kernel; its streaming form when lists and factor do not fit one CU's LDS
+    if (hmpc_lds_bytes(p, 0, 0) > 160 * 1024 || getenv("HMPC_FORCE_BIG")) {
+        if (nw == 1) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 1>, 1, 0, 1};
+        if (nw == 2) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 2>, 2, 0, 1};
+        return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>, 4, 0, 1};
+    }
+    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, 1, 0, 0};
+    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, 2, 0, 0};
+    return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, 4, 0, 0};
 }
 #undef HMPC_TRY
 #endif
