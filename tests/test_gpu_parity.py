@@ -65,6 +65,33 @@ def test_frontier_parity_with_oracle(fixture, T, terminal, count, p_one):
     _compare(hip, hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix), T, fix)
 
 
+@pytest.mark.parametrize('waves', ['1', '2', '4'])
+@pytest.mark.parametrize('fixture,T', [('cart_pole_with_walls', 20), ('cart_pole_with_walls', 40), ('cart_pole_one_wall', 40)])
+def test_every_kernel_instantiation(monkeypatch, fixture, T, waves):
+    # 1 / 2 / 4 waves per node select different compile-time kernels (row-slot layouts differ with the
+    # number of lanes); the batch-size rule would only ever pick one of them for a test-sized frontier
+    hip = make_controller(fixture, T=T, backend='hip')
+    orc = make_controller(fixture, T=T, backend='oracle', threads=8)
+    fix = random_prefix_frontier(T, hip.mld.nub, 40, p_one=0.1, seed0=9000)
+    fix[0, :] = -1
+    monkeypatch.setenv('HMPC_WAVES', waves)
+    res = hip.qp.solve_batch(X0, fix)
+    monkeypatch.delenv('HMPC_WAVES')
+    _compare(hip, res, orc.qp.solve_batch(X0, fix), T, fix)
+
+
+def test_generic_kernel_forced_on_cart_pole(monkeypatch):
+    # the run-time-sized kernel (list row map, LDS factor) on the reference's system
+    monkeypatch.setenv('HMPC_FORCE_GENERIC', '1')
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    monkeypatch.delenv('HMPC_FORCE_GENERIC')
+    orc = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
+    for count in (32, 600):                                  # 4 waves and 1 wave per node
+        fix = random_prefix_frontier(20, 4, count, p_one=0.2, seed0=11000)
+        fix[0, :] = -1
+        _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix)
+
+
 def test_per_node_initial_states():
     hip = make_controller('cart_pole_with_walls', T=10, backend='hip')
     orc = make_controller('cart_pole_with_walls', T=10, backend='oracle', threads=8)
