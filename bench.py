@@ -75,6 +75,24 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
         ws = np.array([v[1:] for v in st['nodes_ws']])
         out[label] = {'value': len(seeds) * steps / dt, 'warm_solves_per_step_mean': float(ws.mean()),
                       'cover_min_max': [int(min(min(v) for v in st['len_ws'])), int(max(max(v) for v in st['len_ws']))]}
+    # (c) one loop through the reference-shaped API (controller.feedback = feedforward + construct_warm_start),
+    # with speculative expansion: the descendants of every selected node down to one stage of binaries are
+    # solved in the same launch, so a warm-started step needs a couple of launches instead of one per level
+    for label, depth in (('single_loop_feedback_api', 0), ('single_loop_feedback_api_speculative', ctrl.mld.nub)):
+        np.random.seed(0)
+        x, ws, dt, rounds, solves = np.array([0., 0., 1., 0.]), None, 0., [], []
+        for k in range(steps + 1):
+            e = 0.001 * np.random.randn(4) * x_max
+            st = {}
+            t0 = time.perf_counter()
+            u, ws, info = ctrl.feedback(x, warm_start=ws, e0=e, frontier_width=8, speculation_depth=depth, stats=st)
+            if k > 0:
+                dt += time.perf_counter() - t0
+                rounds.append(st['rounds'])
+                solves.append(info['qp_solves'])
+            x = info['x1']
+        out[label] = {'value': steps / dt, 'launches_per_step_mean': float(np.mean(rounds)),
+                      'warm_solves_per_step_mean': float(np.mean(solves))}
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
 

@@ -155,3 +155,31 @@ def test_results_do_not_depend_on_batch_or_threads():
     a = ctrl.qp.solve_batch(x0, fix)
     b = OracleBatchedQP(ctrl.problem_data(), threads=4).solve_batch(x0, fix[::-1].copy())
     assert np.array_equal(a['obj'], b['obj'][::-1]) and np.array_equal(a['dual'], b['dual'][::-1])
+
+
+def test_speculative_expansion_changes_launches_not_results():
+    # descendants solved ahead of time in the same launch; the search must consume
+    # the same results in the same order (same incumbent, leaves, solve count), in fewer launches
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle', threads=8)
+    x0 = np.array([0., 0., .5, 0.])
+    base_stats, spec_stats = {}, {}
+    sol0, leaves0, solves0, _ = ctrl.feedforward(x0, printing_period=None, stats=base_stats)
+    sol1, leaves1, solves1, _ = ctrl.feedforward(x0, printing_period=None, speculation_depth=4, stats=spec_stats)
+    assert solves0 == solves1 == 80 and len(leaves0) == len(leaves1) == 41
+    assert [sorted(l.identifier.items()) for l in leaves0] == [sorted(l.identifier.items()) for l in leaves1]
+    assert [l.lb for l in leaves0] == [l.lb for l in leaves1]
+    assert sol0.objective == sol1.objective
+    assert np.array_equal(np.array(sol0.variables['ub']), np.array(sol1.variables['ub']))
+    assert base_stats['rounds'] == 80 and base_stats['speculative'] == 0
+    assert spec_stats['rounds'] < 30
+    assert spec_stats['launched'] >= solves1 and spec_stats['wasted'] == spec_stats['launched'] - solves1
+    # warm-started step: one stage of new binaries, the dive collapses into a couple of launches
+    e0 = np.zeros(4)
+    ws = ctrl.construct_warm_start(leaves0, x0, sol0.variables['uc'][0], sol0.variables['ub'][0], e0)[0]
+    x1 = sol0.variables['x'][1]
+    a_stats, b_stats = {}, {}
+    import copy
+    sa = ctrl.feedforward(x1, warm_start=copy.deepcopy(ws), printing_period=None, stats=a_stats)
+    sb = ctrl.feedforward(x1, warm_start=copy.deepcopy(ws), printing_period=None, speculation_depth=4, stats=b_stats)
+    assert sa[2] == sb[2] and sa[0].objective == sb[0].objective
+    assert b_stats['rounds'] < a_stats['rounds']

@@ -97,6 +97,8 @@ def branch_and_bound(
         batch_solver=None,
         frontier_width=1,
         incumbent_exchange=None,
+        speculation=None,
+        stats=None,
         **kwargs
         ):
     '''
@@ -120,6 +122,16 @@ def branch_and_bound(
         Multi-GPU hook, called once per round by every rank: returns the minimum of the upper
         bound and the total number of open candidates over all ranks (``distributed.py``).
         The search ends when no rank has a candidate left.
+    speculation : function identifier -> list of identifiers, optional
+        Speculative multi-level expansion (needs ``batch_solver``): descendants of a node that are
+        solved in the same launch as the node itself, before it is known whether the search will
+        reach them.  Their results wait in a cache and are consumed, unchanged, when (and only
+        when) the search selects that node -- the sequence of consumed results, hence incumbent,
+        leaves and the returned number of solves, is exactly that of the search without
+        speculation; only the number of kernel launches (rounds) drops.
+    stats : dict, optional
+        Filled with 'rounds' (batch_solver calls), 'launched' (nodes sent to the solver),
+        'speculative' (of those, nodes solved ahead of time) and 'wasted' (never consumed).
 
     Returns
     -------
@@ -134,6 +146,11 @@ def branch_and_bound(
     printer = Printer(printing_period)
     printer.initialize(warm_start, tol)
     width = max(1, int(frontier_width))
+    cache = {}                      # identifier key -> result of a speculative solve
+    rounds = launched = speculative = 0
+
+    def key(identifier):
+        return tuple(sorted(identifier.items()))
 
     while True:
         candidates = [l for l in leaves if l.lb < ub - tol]
@@ -163,8 +180,28 @@ def branch_and_bound(
                 pool.remove(pick)
 
         if batch_solver is not None:
-            for node, result in zip(frontier, batch_solver(frontier, cutoff)):
-                node._take(result)
+            todo = [node for node in frontier if key(node.identifier) not in cache]
+            ahead = []
+            if speculation is not None and todo:
+                seen = set(key(node.identifier) for node in todo)
+                for node in todo:
+                    for identifier in speculation(node.identifier):
+                        k = key(identifier)
+                        if k not in cache and k not in seen:
+                            seen.add(k)
+                            ahead.append(Node(identifier))
+            if todo:
+                results = batch_solver(todo + ahead, cutoff)
+                rounds += 1
+                launched += len(todo) + len(ahead)
+                speculative += len(ahead)
+                for node, result in zip(todo, results):
+                    node._take(result)
+                for node, result in zip(ahead, results[len(todo):]):
+                    cache[key(node.identifier)] = result
+            for node in frontier:
+                if node not in todo:
+                    node._take(cache.pop(key(node.identifier)))
         else:
             for node in frontier:
                 node.solve(solver, cutoff)
@@ -185,6 +222,8 @@ def branch_and_bound(
         printer.update(leaves, ub, solves)
 
     printer.finalize(solves, ub)
+    if stats is not None:
+        stats.update(rounds=rounds, launched=launched, speculative=speculative, wasted=len(cache))
     return incumbent, leaves, solves, solver_time
 
 

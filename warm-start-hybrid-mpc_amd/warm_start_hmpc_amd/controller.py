@@ -177,7 +177,12 @@ class HybridModelPredictiveController(object):
         ``gurobi_params`` is accepted for drop-in compatibility and ignored
         (there is no Gurobi); extra keyword arguments go to
         ``branch_and_bound`` (``tol``, ``warm_start``, ``printing_period``,
-        ``frontier_width`` ...).
+        ``frontier_width``, ``stats`` ...).  ``speculation_depth=k`` solves, together
+        with every selected node, its descendants down to k more binaries
+        (2 + 4 + ... + 2^k nodes per selected node) in the same kernel launch;
+        the search consumes them only if it gets there, so its result is
+        unchanged and only the number of launches per MPC step drops
+        (the serial dive becomes a GPU-sized batch).
 
         Returns
         -------
@@ -199,8 +204,20 @@ class HybridModelPredictiveController(object):
         def brancher(parent):
             return self._brancher(parent, branch_rule)
 
+        depth = int(kwargs.pop('speculation_depth', 0))
+        n_binaries = self.T * self.mld.nub
+
+        def speculation(identifier):
+            level, out = [identifier], []
+            for _ in range(depth):
+                level = [{**ident, **branch} for ident in level if len(ident) < n_binaries
+                         for branch in branch_rule(ident, self.mld.nub)]
+                out.extend(level)
+            return out
+
         incumbent, leaves, qp_solves, solver_time = branch_and_bound(
-            solver, search_rule, brancher, batch_solver=batch_solver, **kwargs)
+            solver, search_rule, brancher, batch_solver=batch_solver,
+            speculation=speculation if depth > 0 else None, **kwargs)
         if incumbent is None:
             return None, leaves, qp_solves, solver_time
         return incumbent.extra.primal, leaves, qp_solves, solver_time
