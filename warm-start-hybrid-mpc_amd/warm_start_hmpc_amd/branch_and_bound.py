@@ -150,7 +150,7 @@ def branch_and_bound(
     rounds = launched = speculative = 0
 
     def key(identifier):
-        return tuple(sorted(identifier.items()))
+        return frozenset(identifier.items())
 
     while True:
         candidates = [l for l in leaves if l.lb < ub - tol]

@@ -191,7 +191,8 @@ class HybridModelPredictiveController(object):
         x0 = np.asarray(x0, dtype=np.float64)
 
         def unpack(solution, share):
-            return solution.primal.objective, solution.primal.binary_feasible, share, solution
+            objective, binary_feasible = solution.objective_and_feasibility()
+            return objective, binary_feasible, share, solution
 
         def solver(identifier, cutoff, extra):
             solution, solve_time = self._solve_subproblem(identifier, x0)

@@ -13,20 +13,58 @@ import numpy as np
 class SubproblemSolution(object):
 
     def __init__(self, primal, dual, active_set=None):
-        self.primal = primal
-        self.dual = dual
+        self._primal = primal
+        self._dual = dual
+        self._rows = None
         # the reference hands a simplex basis from parent to child when Gurobi
         # runs its dual simplex (subproblem_solution.py:38-43); the batched
         # interior-point kernels have no basis, the slot stays None
         self.active_set = active_set
 
+    # The containers are cut out of the flat result rows on first use: a batched round returns
+    # many nodes (speculative ones included) of which branch and bound opens only a few.
+    def _build(self):
+        layout, fix_row, obj, dual_obj, primal_row, dual_row = self._rows
+        self._rows = None
+        self._primal = PrimalSolution.from_row(layout, fix_row, obj, primal_row, not np.isfinite(obj))
+        self._dual = DualSolution.from_row(layout, dual_obj, dual_row)
+
+    @property
+    def primal(self):
+        if self._rows is not None:
+            self._build()
+        return self._primal
+
+    @primal.setter
+    def primal(self, value):
+        if self._rows is not None:
+            self._build()
+        self._primal = value
+
+    @property
+    def dual(self):
+        if self._rows is not None:
+            self._build()
+        return self._dual
+
+    @dual.setter
+    def dual(self, value):
+        if self._rows is not None:
+            self._build()
+        self._dual = value
+
+    def objective_and_feasibility(self):
+        """(primal objective, binary feasible) without building the containers."""
+        if self._rows is not None:
+            _, fix_row, obj, _, _, _ = self._rows
+            return (float(obj) if np.isfinite(obj) else np.inf), bool(np.all(np.asarray(fix_row) >= 0))
+        return self._primal.objective, self._primal.binary_feasible
+
     @staticmethod
     def from_rows(layout, fix_row, obj, dual_obj, status, primal_row, dual_row):
-        """Builds the record of one node from one row of a batch result."""
-        infeasible = not np.isfinite(obj)
-        primal = PrimalSolution.from_row(layout, fix_row, obj, primal_row, infeasible)
-        dual = DualSolution.from_row(layout, dual_obj, dual_row)
-        sol = SubproblemSolution(primal, dual)
+        """Record of one node from one row of a batch result (the rows are kept by reference)."""
+        sol = SubproblemSolution(None, None)
+        sol._rows = (layout, fix_row, obj, dual_obj, primal_row, dual_row)
         sol.status = int(status)
         return sol
 
