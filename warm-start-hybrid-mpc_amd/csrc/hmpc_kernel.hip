@@ -1,25 +1,30 @@
 // hmpc_kernel.hip -- batched QP relaxations of hybrid-MPC branch-and-bound nodes on gfx950.
 //
-// One wavefront (64 lanes) owns one node's QP from start to finish:
-//   * node-independent data that every sweep re-reads -- [A B], the cost Hessians, the scaled
-//     right-hand sides and the sparse row / column / Gram lists of the regular stage -- is staged
-//     into LDS once per workgroup; every stage uses them.  The terminal-set rows (a dense block that
-//     exists only at the last stage and is masked in most solves) are kept apart, appended after all
-//     stage rows, in global memory (read-only, L2 resident), and touched only when they are active;
-//   * everything indexed by stage -- iterate, Newton directions, Riccati factor (gain, inverse
-//     input Hessian, cost-to-go per stage) -- and the per-row vectors that other lanes must see
-//     (multipliers z, barrier weights D = z/s, scaled right-hand side e) live in LDS, addressed
-//     through address-space-3 pointers so that every access is a ds_read / ds_write;
-//   * per-row temporaries that only their own lane touches (slack s, row residual, the constant
-//     direction, affine products) live in a per-workgroup slab of global memory, written and read
-//     coalesced (row r <-> lane r % 64), small enough to stay in L2 / Infinity Cache;
-//   * reductions (complementarity, residual norms, step length) are wave shuffles -- no atomics,
-//     so a node's result does not depend on the batch it is solved in.
+// One workgroup of 1, 2 or 4 wavefronts owns one node's QP from start to finish (the host picks the
+// number of waves from the batch size: one wave per node for throughput, more for latency):
+//   * everything indexed by stage -- iterate, two sets of Newton directions, residuals, the Riccati
+//     factor (elimination multipliers, reciprocal pivots, cost-to-go) -- and the one row-indexed vector
+//     other lanes must see (in turn z, D = z/s, D .* rhs, dz) live in LDS, addressed through
+//     address-space-3 pointers so that every access is a ds_read / ds_write; node-independent data
+//     ([A B], Hessians, column and Gram lists of the regular stage) is staged there once per workgroup;
+//   * per-row state (slack, multiplier / barrier weight, step, affine product) lives in REGISTERS of
+//     the lane that owns the row.  For the compile-time shapes a lane owns the same local row in every
+//     slot, so the row's coefficients are registers too (RowMapS); the generic kernel walks sparse
+//     lists and keeps the row state in a per-workgroup slab of global memory (RowMapL);
+//   * the sequential recursions (stage elimination, forward / back substitution) run in registers of
+//     wave 0 with v_readlane broadcasts, software pipelined against the LDS fetches of the next stage;
+//   * the terminal-set rows (a dense block that exists only at the last stage and is masked in most
+//     solves) stay in global memory (read-only, L2 resident) and are touched only when active;
+//   * reductions (complementarity, residual norms, step length) are wave shuffles plus one LDS
+//     exchange between waves -- no atomics, so a node's result does not depend on the batch it is in;
+//   * problems too large for LDS take the generic kernel's streaming form (lists and factor in global
+//     memory, Dims::kBig).
 //
 // Algorithm (same as the CPU oracle, oracle/hsde_qp.c): Mehrotra predictor-corrector on the
 // homogeneous embedding of the QP; each KKT solve is a Riccati sweep over the horizon with fixed
-// binaries handled as prescribed variables; one step of iterative refinement on the final
-// direction; terminal-set rows are tried masked first ("lazy terminal set").
+// binaries handled as prescribed variables, the factor kept in substitution form; up to two steps of
+// iterative refinement on the combined direction; terminal-set rows are tried masked first ("lazy
+// terminal set").
 //
 // The reference (warm_start_hmpc/controller.py:229-271 -> bounded_qp.py:200-228) solves these QPs
 // one at a time inside Gurobi; conventions of the output record follow
