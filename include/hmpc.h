@@ -50,7 +50,7 @@ extern "C" {
 #define HMPC_OK 0
 #define HMPC_EINVAL -1 /* bad argument (sizes, null pointers) */
 #define HMPC_EDEVICE -2 /* HIP error; text in hmpc_last_error() */
-#define HMPC_ETOOBIG -3 /* problem does not fit the LDS-resident kernel */
+#define HMPC_ETOOBIG -3 /* the per-node vectors exceed one CU's LDS even with lists and factor in global memory */
 
 /* Node-independent problem data (replaces the Gurobi model built by controller.py:119-184).
  * nc  = rows of [F G];  ncT = rows of [F_Tm1 G_Tm1] (= nc + terminal facets, controller.py:85-87).
@@ -118,6 +118,36 @@ int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_stride, const 
  * handle's device; the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream). */
 int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B,
                             const hmpc_result *d_out, void *stream);
+
+/* ---- Warm-start node shift (reference: controller.py:431-564 construct_warm_start, :615-721) --------
+ * After an MPC step the leaves of the branch-and-bound tree become the initial cover of the next
+ * step's tree: leaves that disagree with the applied binaries are dropped (controller.py:566-613),
+ * identifiers and multipliers move one stage towards the present, the last stage is filled through
+ * two precomputed maps (:635-666), and the dual objective -- the leaf's new lower bound -- changes
+ * by the pi-sum of :668-721, then by the model error and the clipping / reopening rule of :541-558.
+ * One wavefront per leaf; the kernel is memory bound (it reads and writes one dual row per leaf). */
+typedef struct hmpc_shift_maps {
+    const double *M_mu;  /* nc x ncT : mu'_{T-2}  = M_mu  mu_{T-1}   (controller.py:186-227 _update_mu) */
+    const double *M_rho; /* nq x nqT : rho'_{T-1} = M_rho rho_T                                        */
+    const double *V;     /* nub x nu : the binaries of an input vector (MLDSystem.V)                    */
+} hmpc_shift_maps;
+int hmpc_set_shift_maps(hmpc_handle *h, const hmpc_shift_maps *maps);
+
+/* Shifts B leaves that belong to K trees (MPC instances advanced together).  owner[b] in [0, K) is the
+ * tree of leaf b; x0, u0, e0 hold K rows: the state the step started from, the applied input (uc, ub)
+ * and the model error of the step.  Per leaf in: fix (T*nub int8), lower bound (+inf: proved infeasible),
+ * dual row, dual objective.  Per leaf out: shifted fix / dual row / dual objective, the new lower bound,
+ * and flags: bit 0 = keep (the leaf agrees with the applied binaries; otherwise the other outputs are
+ * undefined), bit 1 = reopened (its infeasibility proof did not survive the shift: lb = 0, multipliers
+ * to be ignored).  Host-pointer form: copies in, runs, copies out. */
+int hmpc_shift_batch(hmpc_handle *h, int32_t B, int32_t K, const int32_t *owner, const double *x0, const double *u0,
+                     const double *e0, const int8_t *fix, const double *lb, const double *dual, const double *dual_obj,
+                     int8_t *fix_out, double *lb_out, double *dual_out, double *dual_obj_out, uint8_t *flags);
+/* Device-pointer form, asynchronous on `stream`. */
+int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t *d_owner, const double *d_x0,
+                            const double *d_u0, const double *d_e0, const int8_t *d_fix, const double *d_lb,
+                            const double *d_dual, const double *d_dual_obj, int8_t *d_fix_out, double *d_lb_out,
+                            double *d_dual_out, double *d_dual_obj_out, uint8_t *d_flags, void *stream);
 
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);

@@ -4,7 +4,7 @@
     python profiles/summarise.py stats  <rocprof dir> <out.csv>            # kernel_stats.csv of a --kernel-trace --stats run
     python profiles/summarise.py pmc    <out.json> <rocprof dir> [...]     # counter_collection.csv of --pmc runs
 
-For counters the mean per launch of `hmpc_qp_kernel` is stored; launches that belong to the
+For counters the mean per launch of `hmpc_qp_kernel` (and, under 'shift_kernel', of `hmpc_shift_kernel`) is stored; launches that belong to the
 warm-up are included (the kernel does the same work in each).  FETCH_SIZE / WRITE_SIZE are in
 KiB as rocprofv3 reports them; `*_bytes_corrected` applies the gfx950 correction of
 MI355X_MICROARCH.md (section HBM): FETCH_SIZE tallies 128-B requests at 64 B => x2; WRITE_SIZE exact.
@@ -29,12 +29,22 @@ def stats(d, out):
 
 
 def pmc(out, dirs):
+    res = _pmc(dirs, 'hmpc_qp_kernel')
+    shift = _pmc(dirs, 'hmpc_shift_kernel', required=False)
+    if shift:
+        res['shift_kernel'] = shift      # the warm-start shift (bench.py: 65536 leaves per launch)
+    with open(out, 'w') as fh:
+        json.dump(res, fh, indent=1)
+    print(json.dumps(res, indent=1))
+
+
+def _pmc(dirs, kernel, required=True):
     acc = {}
     for d in dirs:
         for f in find(d, '_counter_collection.csv'):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
-                    if 'hmpc_qp_kernel' not in row['Kernel_Name']:
+                    if kernel not in row['Kernel_Name']:
                         continue
                     a = acc.setdefault(row['Counter_Name'], {'sum': 0.0, 'launches': 0, 'kernel': row['Kernel_Name'],
                                                              'vgpr': row['VGPR_Count'], 'agpr': row['Accum_VGPR_Count'],
@@ -55,9 +65,7 @@ def pmc(out, dirs):
         res['WRITE_SIZE']['bytes_corrected'] = res['WRITE_SIZE']['mean_per_launch'] * 1024
     if 'FETCH_SIZE' in res and 'WRITE_SIZE' in res:
         res['hbm_traffic_bytes_per_launch'] = res['FETCH_SIZE']['bytes_corrected'] + res['WRITE_SIZE']['bytes_corrected']
-    with open(out, 'w') as fh:
-        json.dump(res, fh, indent=1)
-    print(json.dumps(res, indent=1))
+    return res
 
 
 if __name__ == '__main__':

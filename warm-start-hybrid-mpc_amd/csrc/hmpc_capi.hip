@@ -16,7 +16,8 @@
 
 #include "hmpc_device.h"
 
-#include "hmpc_kernel.hip" // one translation unit: the kernel is launched from this file
+#include "hmpc_kernel.hip" // one translation unit: the kernels are launched from this file
+#include "hmpc_shift.hip"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
@@ -43,6 +44,8 @@ struct hmpc_handle {
     DevProb dp{};
     std::vector<void *> allocs;
     double *rows_ws = nullptr;
+    void *d_shift = nullptr; // staging of the host-pointer shift
+    size_t shift_staged = 0;
     double *trace = nullptr;
     size_t lds = 0;
     int max_grid = 0, last_grid = 0;
@@ -276,6 +279,10 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         if ((rc = upload(h, reg.C, &p.Creg))) break;
         if ((rc = upload(h, ccv, &p.ccv))) break;
         if ((rc = upload(h, cci, &p.cci))) break;
+        if ((rc = upload(h, vec(q->F, (size_t)q->nc * nx), &p.F_raw))) break;
+        if ((rc = upload(h, vec(q->G, (size_t)q->nc * nu), &p.G_raw))) break;
+        if ((rc = upload(h, vec(q->h, (size_t)q->nc), &p.h_raw))) break;
+        if ((rc = upload(h, vec(q->h_Tm1, (size_t)q->ncT), &p.hT_raw))) break;
         if ((rc = upload(h, Ct, &p.Ct))) break;
         if ((rc = upload(h, ht, &p.ht))) break;
         if ((rc = upload(h, sct, &p.sct))) break;
@@ -348,6 +355,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     (void)hipSetDevice(h->device);
     for (void *d : h->allocs) (void)hipFree(d);
     if (h->rows_ws) (void)hipFree(h->rows_ws);
+    if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->trace) (void)hipFree(h->trace);
     for (void *d : {h->d_x0, h->d_fix, h->d_obj, h->d_dobj, h->d_status, h->d_iters, h->d_primal, h->d_dual})
         if (d) (void)hipFree(d);
@@ -360,6 +368,103 @@ extern "C" int hmpc_record_sizes(const hmpc_handle *h, int32_t *n_primal, int32_
     if (!h) return fail(HMPC_EINVAL, "null handle");
     if (n_primal) *n_primal = h->dp.n_primal;
     if (n_dual) *n_dual = h->dp.n_dual;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_set_shift_maps(hmpc_handle *h, const hmpc_shift_maps *m)
+{
+    g_err.clear();
+    if (!h || !m || !m->M_mu || !m->M_rho || !m->V) return fail(HMPC_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    DevProb &p = h->dp;
+    int rc;
+    auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
+    if ((rc = upload(h, vec(m->M_mu, (size_t)p.nc * p.ncL), &p.shift_Mmu))) return rc;
+    if ((rc = upload(h, vec(m->M_rho, (size_t)p.nq * p.nqT), &p.shift_Mrho))) return rc;
+    if ((rc = upload(h, vec(m->V, (size_t)p.nub * p.nu), &p.shift_V))) return rc;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t *d_owner, const double *d_x0,
+                                       const double *d_u0, const double *d_e0, const int8_t *d_fix, const double *d_lb,
+                                       const double *d_dual, const double *d_dual_obj, int8_t *d_fix_out, double *d_lb_out,
+                                       double *d_dual_out, double *d_dual_obj_out, uint8_t *d_flags, void *stream)
+{
+    g_err.clear();
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    if (!h->dp.shift_Mmu) return fail(HMPC_EINVAL, "hmpc_set_shift_maps has not been called");
+    if (B < 0 || K < 1) return fail(HMPC_EINVAL, "bad leaf or tree count");
+    if (B == 0) return HMPC_OK;
+    if (!d_owner || !d_x0 || !d_u0 || !d_e0 || !d_fix || !d_lb || !d_dual || !d_dual_obj || !d_fix_out || !d_lb_out ||
+        !d_dual_out || !d_dual_obj_out || !d_flags)
+        return fail(HMPC_EINVAL, "null argument");
+    if (d_dual == d_dual_out || d_fix == d_fix_out) return fail(HMPC_EINVAL, "the shift is not in place");
+    HIPCHK(hipSetDevice(h->device));
+    ShiftArgs a{B, K, d_owner, d_x0, d_u0, d_e0, d_fix, d_lb, d_dual, d_dual_obj, d_fix_out, d_lb_out, d_dual_out, d_dual_obj_out, d_flags};
+    // persistent workgroups: enough to fill the device, each wave walks leaves with stride grid * SHIFT_WAVES
+    const bool staged = hmpc_shift_lds_doubles(h->dp, true) * sizeof(double) <= 64 * 1024;
+    const size_t lds = hmpc_shift_lds_doubles(h->dp, staged) * sizeof(double);
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) return fail(HMPC_ETOOBIG, "the shift's last-stage vectors exceed one CU's LDS");
+    int grid = (cus > 0 ? cus : 256) * per_cu;
+    const int need = (B + SHIFT_WAVES - 1) / SHIFT_WAVES;
+    if (grid > need) grid = need;
+    if (staged) {
+        if (lds > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)hmpc_shift_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(hmpc_shift_kernel<true>, dim3(grid), dim3(64 * SHIFT_WAVES), lds, (hipStream_t)stream, h->dp, a);
+    } else {
+        hipLaunchKernelGGL(hmpc_shift_kernel<false>, dim3(grid), dim3(64 * SHIFT_WAVES), lds, (hipStream_t)stream, h->dp, a);
+    }
+    HIPCHK(hipGetLastError());
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_shift_batch(hmpc_handle *h, int32_t B, int32_t K, const int32_t *owner, const double *x0, const double *u0,
+                                const double *e0, const int8_t *fix, const double *lb, const double *dual, const double *dual_obj,
+                                int8_t *fix_out, double *lb_out, double *dual_out, double *dual_obj_out, uint8_t *flags)
+{
+    g_err.clear();
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    if (B < 0 || K < 1) return fail(HMPC_EINVAL, "bad leaf or tree count");
+    if (B == 0) return HMPC_OK;
+    if (!owner || !x0 || !u0 || !e0 || !fix || !lb || !dual || !dual_obj || !fix_out || !lb_out || !dual_out || !dual_obj_out || !flags)
+        return fail(HMPC_EINVAL, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    const DevProb &p = h->dp;
+    const size_t nf = (size_t)B * p.T * p.nub, nd = (size_t)B * p.n_dual * sizeof(double), nb = (size_t)B * sizeof(double);
+    // one staging block: inputs then outputs
+    struct Part { size_t bytes; const void *src; void *dst; size_t off; };
+    Part parts[] = {{(size_t)B * 4, owner, nullptr, 0}, {(size_t)K * p.nx * 8, x0, nullptr, 0}, {(size_t)K * p.nu * 8, u0, nullptr, 0},
+                    {(size_t)K * p.nx * 8, e0, nullptr, 0}, {nf, fix, nullptr, 0}, {nb, lb, nullptr, 0}, {nd, dual, nullptr, 0},
+                    {nb, dual_obj, nullptr, 0}, {nf, nullptr, fix_out, 0}, {nb, nullptr, lb_out, 0}, {nd, nullptr, dual_out, 0},
+                    {nb, nullptr, dual_obj_out, 0}, {(size_t)B, nullptr, flags, 0}};
+    size_t total = 0;
+    for (Part &q : parts) { q.off = total; total += (q.bytes + 255) / 256 * 256; }
+    if (total > h->shift_staged) {
+        if (h->d_shift) (void)hipFree(h->d_shift);
+        h->d_shift = nullptr;
+        h->shift_staged = 0;
+        HIPCHK(hipMalloc(&h->d_shift, total));
+        h->shift_staged = total;
+    }
+    char *base = (char *)h->d_shift;
+    for (const Part &q : parts)
+        if (q.src) HIPCHK(hipMemcpyAsync(base + q.off, q.src, q.bytes, hipMemcpyHostToDevice, 0));
+    const int rc = hmpc_shift_batch_device(h, B, K, (const int32_t *)(base + parts[0].off), (const double *)(base + parts[1].off),
+                                           (const double *)(base + parts[2].off), (const double *)(base + parts[3].off),
+                                           (const int8_t *)(base + parts[4].off), (const double *)(base + parts[5].off),
+                                           (const double *)(base + parts[6].off), (const double *)(base + parts[7].off),
+                                           (int8_t *)(base + parts[8].off), (double *)(base + parts[9].off),
+                                           (double *)(base + parts[10].off), (double *)(base + parts[11].off),
+                                           (uint8_t *)(base + parts[12].off), nullptr);
+    if (rc != HMPC_OK) return rc;
+    for (const Part &q : parts)
+        if (q.dst) HIPCHK(hipMemcpyAsync(q.dst, base + q.off, q.bytes, hipMemcpyDeviceToHost, 0));
+    HIPCHK(hipStreamSynchronize(0));
     return HMPC_OK;
 }
 

@@ -104,6 +104,11 @@ class BatchedMPC(object):
         self.o_ub = cut['nu_ub'][0].start
         self.cut = cut
         self.lay = lay
+        # the GPU backend shifts the leaves of all trees in one kernel launch (hmpc_shift_batch, csrc/hmpc_shift.hip);
+        # a backend without it (the CPU oracle used by the tests) takes the numpy form below
+        self.device_shift = hasattr(controller.qp, 'shift_batch')
+        if self.device_shift:
+            controller.qp.set_shift_maps(controller._update['mu'], controller._update['rho'], controller.mld.V)
 
     # ------------------------------------------------------------------
     def feedforward_many(self, x0s, warm_starts=None, frontier_width=8, tol=0.):
@@ -235,6 +240,27 @@ class BatchedMPC(object):
         new_fix = np.concatenate((fix[:, nub:], np.full((n, nub), -1, dtype=np.int8)), axis=1)
         return NodeArrays(new_fix, lb, new, obj, has_dual)
 
+    def construct_warm_start_many(self, leaves_list, x0s, u0s, e0s):
+        """Node shift for the leaves of K trees at once: one kernel launch on the GPU backend, else the numpy form per tree.
+
+        leaves_list : list of NodeArrays;  x0s, e0s : (K, nx);  u0s : (K, nu) applied inputs (uc, ub).
+        Returns a list of NodeArrays (the warm starts).
+        """
+        if not self.device_shift:
+            return [self.construct_warm_start(lv, x0s[k], u0s[k][:self.nuc], u0s[k][self.nuc:], e0s[k])
+                    for k, lv in enumerate(leaves_list)]
+        sizes = [len(lv) for lv in leaves_list]
+        owner = np.repeat(np.arange(len(leaves_list), dtype=np.int32), sizes)
+        cat = lambda name: np.concatenate([getattr(lv, name) for lv in leaves_list])
+        r = self.c.qp.shift_batch(owner, x0s, u0s, e0s, cat('fix'), cat('lb'), cat('dual'), cat('dobj'))
+        has_dual = cat('has_dual') & ~r['reopened']
+        out, o = [], 0
+        for n in sizes:
+            k = np.flatnonzero(r['keep'][o:o + n]) + o
+            out.append(NodeArrays(r['fix'][k], r['lb'][k], r['dual'][k], r['dual_obj'][k], has_dual[k]))
+            o += n
+        return out
+
     # ------------------------------------------------------------------
     def closed_loop(self, x0, n_steps, e_sd=0., seeds=(0,), x_max=None, frontier_width=8, cold_too=False, log=None):
         """Closed-loop Monte-Carlo study in the shape of statistical_analysis.py:93-207.
@@ -261,7 +287,7 @@ class BatchedMPC(object):
                 break
             cold = self.feedforward_many(xs[active], None, frontier_width) if cold_too else None
             warm = self.feedforward_many(xs[active], [ws[k] for k in active], frontier_width)
-            still = []
+            still, shifted = [], []
             for j, k in enumerate(active):
                 r = warm[j]
                 if cold is not None:
@@ -274,7 +300,15 @@ class BatchedMPC(object):
                 if not np.isfinite(r['objective']):
                     continue                        # infeasible: the simulation ends here
                 e_t = e_sd * rngs[k].randn(self.nx) * x_max
-                ws[k] = self.construct_warm_start(r['leaves'], xs[k], r['uc'][0], r['ub'][0], e_t)
+                shifted.append((j, k, e_t))
+            if shifted:
+                new_ws = self.construct_warm_start_many(
+                    [warm[j]['leaves'] for j, _, _ in shifted], np.array([xs[k] for _, k, _ in shifted]),
+                    np.array([np.concatenate((warm[j]['uc'][0], warm[j]['ub'][0])) for j, _, _ in shifted]),
+                    np.array([e for _, _, e in shifted]))
+            for (j, k, e_t), w in zip(shifted, new_ws if shifted else []):
+                r = warm[j]
+                ws[k] = w
                 stats['len_ws'][k].append(len(ws[k]))
                 stats['costs'][k].append(r['objective'])
                 stats['errors'][k].append(e_t)

@@ -38,6 +38,10 @@ class _Result(ctypes.Structure):
                 ('iters', ctypes.c_void_p), ('primal', ctypes.c_void_p), ('dual', ctypes.c_void_p)]
 
 
+class _ShiftMaps(ctypes.Structure):
+    _fields_ = [('M_mu', _dp), ('M_rho', _dp), ('V', _dp)]
+
+
 _lib = None
 
 
@@ -64,12 +68,19 @@ def load_library():
         lib.hmpc_solve_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                                 ctypes.c_int32, ctypes.POINTER(_Result), ctypes.c_void_p]
         lib.hmpc_last_error.restype = ctypes.c_char_p
+        lib.hmpc_set_shift_maps.restype = ctypes.c_int
+        lib.hmpc_set_shift_maps.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ShiftMaps)]
+        lib.hmpc_shift_batch.restype = ctypes.c_int
+        lib.hmpc_shift_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 13
+        lib.hmpc_shift_batch_device.restype = ctypes.c_int
+        lib.hmpc_shift_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 14
         _lib = lib
     return _lib
 
 
 EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info',
-                    'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error')
+                    'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
+                    'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device')
 
 
 class HipBatchedQP(object):
@@ -109,7 +120,8 @@ class HipBatchedQP(object):
         n_primal, n_dual = ctypes.c_int32(), ctypes.c_int32()
         self.lib.hmpc_record_sizes(self.handle, ctypes.byref(n_primal), ctypes.byref(n_dual))
         self.n_primal, self.n_dual = n_primal.value, n_dual.value
-        self.nx, self.nfix = nx, T * nub
+        self.nx, self.nu, self.nfix = nx, nu, T * nub
+        self._shift_ready = False
 
     def __del__(self):
         handle = getattr(self, 'handle', None)
@@ -168,3 +180,66 @@ class HipBatchedQP(object):
         grid, lds = ctypes.c_int32(), ctypes.c_int32()
         self.lib.hmpc_launch_info(self.handle, ctypes.byref(grid), ctypes.byref(lds))
         return grid.value, lds.value
+
+    # ------------------------------------------------------------------
+    # warm-start node shift (controller.py:431-721 of the reference) on the device
+    # ------------------------------------------------------------------
+    def set_shift_maps(self, M_mu, M_rho, V):
+        """Uploads the node-independent maps of the shift: mu'_{T-2} = M_mu mu_{T-1}, rho'_{T-1} = M_rho rho_T
+        (``controller._update``) and the binary selector ``mld.V``."""
+        keep = [np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in (M_mu, M_rho, V)]
+        m = _ShiftMaps(*[a.ctypes.data_as(_dp) for a in keep])
+        self._check(self.lib.hmpc_set_shift_maps(self.handle, ctypes.byref(m)))
+        self._shift_ready = True
+
+    def shift_batch(self, owner, x0, u0, e0, fix, lb, dual, dual_obj):
+        """Shifts B leaves of K trees one stage (host arrays in and out).
+
+        owner : int32 (B,) tree of each leaf;  x0, e0 : (K, nx);  u0 : (K, nu) applied inputs (uc, ub)
+        fix : int8 (B, T*nub);  lb, dual_obj : (B,);  dual : (B, n_dual)
+        Returns dict fix, lb, dual, dual_obj (B rows; rows of dropped leaves are undefined), keep (bool, B),
+        reopened (bool, B), time.
+        """
+        if not self._shift_ready:
+            raise RuntimeError('set_shift_maps has not been called')
+        owner = np.ascontiguousarray(owner, dtype=np.int32)
+        B = owner.size
+        x0, u0, e0 = (np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in (x0, u0, e0))
+        K = x0.shape[0]
+        if x0.shape != (K, self.nx) or e0.shape != (K, self.nx) or u0.shape != (K, self.nu):
+            raise ValueError('x0, e0 must be (K, nx) and u0 (K, nu).')
+        fix = np.ascontiguousarray(fix, dtype=np.int8)
+        lb, dual_obj = np.ascontiguousarray(lb, dtype=np.float64), np.ascontiguousarray(dual_obj, dtype=np.float64)
+        dual = np.ascontiguousarray(dual, dtype=np.float64)
+        if fix.shape != (B, self.nfix) or dual.shape != (B, self.n_dual) or lb.shape != (B,) or dual_obj.shape != (B,):
+            raise ValueError('leaf arrays have inconsistent shapes.')
+        if B and (owner.min() < 0 or owner.max() >= K):
+            raise ValueError('owner out of range.')
+        out = dict(fix=np.empty_like(fix), lb=np.empty(B), dual=np.empty_like(dual), dual_obj=np.empty(B))
+        flags = np.zeros(B, dtype=np.uint8)
+        tic = time.perf_counter()
+        self._check(self.lib.hmpc_shift_batch(self.handle, B, K, owner.ctypes.data, x0.ctypes.data, u0.ctypes.data, e0.ctypes.data,
+                                              fix.ctypes.data, lb.ctypes.data, dual.ctypes.data, dual_obj.ctypes.data,
+                                              out['fix'].ctypes.data, out['lb'].ctypes.data, out['dual'].ctypes.data,
+                                              out['dual_obj'].ctypes.data, flags.ctypes.data))
+        out['time'] = time.perf_counter() - tic
+        out['keep'] = (flags & 1).astype(bool)
+        out['reopened'] = (flags & 2).astype(bool)
+        return out
+
+    def shift_batch_device(self, owner, x0, u0, e0, fix, lb, dual, dual_obj, out, stream=None):
+        """Device-resident form: torch CUDA tensors; ``out`` is a dict of preallocated tensors fix (int8), lb, dual,
+        dual_obj (float64) and flags (uint8: bit 0 keep, bit 1 reopened).  Asynchronous on ``stream``."""
+        import torch
+        if not self._shift_ready:
+            raise RuntimeError('set_shift_maps has not been called')
+        B, K = owner.shape[0], x0.shape[0]
+        for t in (owner, x0, u0, e0, fix, lb, dual, dual_obj, out['fix'], out['lb'], out['dual'], out['dual_obj'], out['flags']):
+            assert t.is_cuda and t.is_contiguous()
+        assert owner.dtype == torch.int32 and fix.dtype == torch.int8 and out['flags'].dtype == torch.uint8
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        self._check(self.lib.hmpc_shift_batch_device(self.handle, B, K, owner.data_ptr(), x0.data_ptr(), u0.data_ptr(), e0.data_ptr(),
+                                                     fix.data_ptr(), lb.data_ptr(), dual.data_ptr(), dual_obj.data_ptr(),
+                                                     out['fix'].data_ptr(), out['lb'].data_ptr(), out['dual'].data_ptr(),
+                                                     out['dual_obj'].data_ptr(), out['flags'].data_ptr(), ctypes.c_void_p(stream)))
