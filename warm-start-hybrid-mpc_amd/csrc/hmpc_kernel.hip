@@ -37,6 +37,9 @@
 #include "hmpc_device.h"
 
 #define WAVE 64
+#ifndef HMPC_KERNEL_ATTR
+#define HMPC_KERNEL_ATTR
+#endif
 #define DEV __device__ __forceinline__
 
 // Diagnostic build only (-DHMPC_STAMPS): cycle stamps per phase of the interior-point loop,
@@ -177,6 +180,7 @@ struct Lds {
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
+    unsigned long long fullfix; // bit t: every binary of stage t < 64 is fixed by the node (wave uniform)
 };
 
 // Problem dimensions: compile-time for the instantiated shapes (index arithmetic folds to
@@ -820,8 +824,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             // The multiplier of row i at pivot j is M(i, pj) / d; by symmetry lane i holds it as
             // col[pj] / d, so every lane keeps the multipliers of its own row and stores them once.
             double myrow[NU], dinv[NU];
-#pragma unroll
-            for (int j = 0; j < NU; j++) {
+            auto pivot = [&](const int j) {
                 const int pj = NX + j;
                 const double d = bcast(col[pj], pj); // 1 at a prescribed pivot: the step below changes nothing
                 if (!(d > 0.0)) bad = 1;
@@ -834,6 +837,16 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 for (int i = 0; i < NZ; i++) {
                     if (i < NX || i > pj) col[i] -= bcast(col[i], pj) * cr; // rows still to be reduced
                 }
+            };
+#pragma unroll
+            for (int j = 0; j < NUC; j++) pivot(j);
+            // a stage whose binaries are all fixed (most stages of a deep node): their pivot steps are no-ops
+            if ((S.fullfix >> t) & 1ull) {
+#pragma unroll
+                for (int j = NUC; j < NU; j++) { myrow[j] = 0.0; dinv[j] = 1.0; }
+            } else {
+#pragma unroll
+                for (int j = NUC; j < NU; j++) pivot(j);
             }
             if (lane < NZ) { // rows of the states: NU entries; row i of the inputs: its i entries (zeros at skipped pivots)
                 ldsd *row = Lm + (lane < NX ? lane * NU : LM_U(NX, NU, lane - NX, 0));
@@ -1080,7 +1093,11 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
             if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
             // forward substitution: the factorisation's row operations applied to the vector
 #pragma unroll
-            for (int j = 0; j < NU; j++) v -= mrow[j] * bcast(v, NX + j);
+            for (int j = 0; j < NUC; j++) v -= mrow[j] * bcast(v, NX + j);
+            if (!((S.fullfix >> t) & 1ull)) { // the binaries' steps are no-ops (zero multipliers) when all are fixed
+#pragma unroll
+                for (int j = NUC; j < NU; j++) v -= mrow[j] * bcast(v, NX + j);
+            }
             if (lane >= NX && lane < NZ) dw[t * NZ + lane] = v; // y = L_u^{-1} m_u, parked in the input slots
             pvr = v;                                            // lanes < NX: p_t
             if (lane < NX) S.pv[t * NX + lane] = v;
@@ -1711,7 +1728,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
 // KF / KB / KT: register slots of the static row map ([F G] rows, bound rows, terminal-set rows) for the
 // compile-time shapes; all zero for the generic kernel (list row map, rows in the global slab).
 template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW>
-__global__ void __launch_bounds__(NW * WAVE)
+__global__ void __launch_bounds__(NW * WAVE) HMPC_KERNEL_ATTR
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
 {
@@ -1790,6 +1807,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.ccv = cval0;
         S.cci = cci0;
         S.term_on = 0;
+        S.fullfix = 0;
     }
     Rows<RS> R;
     R.bind(rows_ws + (size_t)blockIdx.x * 4 * p.Mpad, p.Mpad);
@@ -1800,6 +1818,12 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
         for (int i = lane; i < nx; i += D::kNT) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
         __syncthreads();
+        {
+            const int st = lane & 63;
+            bool all = st < T && nub > 0;
+            for (int bq = 0; bq < nub; bq++) all = all && S.fix[(st < T ? st : 0) * nub + bq] >= 0;
+            S.fullfix = __ballot(all);
+        }
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
