@@ -120,6 +120,23 @@ class HybridModelPredictiveController(object):
             fix[t * nub + i] = int(v)
         return fix
 
+    def bounded_qp(self):
+        """The node QP behind the accessor interface of the reference's ``BoundedQP`` (see ``bounded_qp.py``)."""
+        from .bounded_qp import BoundedQP
+        return BoundedQP(self)
+
+    def _set_bound_binaries(self, identifier, qp):
+        '''
+        Writes the bounds that an identifier imposes on the binaries into the
+        right-hand sides of ``qp`` (a ``BoundedQP`` of this controller), as
+        controller.py:273-298 does on the reference's Gurobi model: the rhs of
+        nu_lb_t is MINUS the lower bound, the rhs of nu_ub_t the upper bound.
+        '''
+        ub_lb, ub_ub = self._get_bound_binaries(identifier)
+        for t in range(self.T):
+            qp.set_constraint_rhs('nu_lb_%d' % t, -ub_lb[t])
+            qp.set_constraint_rhs('nu_ub_%d' % t, ub_ub[t])
+
     def _get_bound_binaries(self, identifier):
         '''
         Lower and upper bounds that an identifier imposes on the binaries,
