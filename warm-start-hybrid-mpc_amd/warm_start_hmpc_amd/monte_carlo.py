@@ -12,6 +12,11 @@ log: ``cs`` cold solves, ``ws`` warm solves, ``ws info`` cover size, ``e`` error
 ``nodes_{cs,ws,len_ws}_sd_<sd>.npy`` so that the numbers can be put next to
 ``notebooks/cart_pole_with_walls/data/`` of the reference.  Gurobi's own MIQP columns (``grb``,
 ``grb_fair``) have no counterpart here.
+
+The simulations are independent: launched under ``torch.distributed.run`` with N ranks (one per GPU),
+rank r advances the simulations r, r + N, r + 2N, ... on its own GPU with no communication during the
+study; at the end the per-simulation statistics are gathered on rank 0, which writes the arrays and the
+summary (the per-step log lines of every rank go to ``solve_log_<sd>.rank<r>.log``).
 """
 import argparse
 import os
@@ -20,7 +25,9 @@ import sys
 import numpy as np
 
 
-def main(argv=None):
+def main(argv=None, backend_factory=None):
+    """``backend_factory`` (problem data -> batched QP backend) is a hook for the CPU tests; the default is the HIP
+    library on this rank's GPU."""
     ap = argparse.ArgumentParser()
     ap.add_argument('--fixture', required=True)
     ap.add_argument('--sims', type=int, default=100)
@@ -34,16 +41,48 @@ def main(argv=None):
     from .mld_system import MLDSystem
     from .controller import HybridModelPredictiveController
     from .batched import BatchedMPC
+    world, rank, local = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if not dist.is_initialized():
+            dist.init_process_group('nccl' if (backend_factory is None and torch.cuda.is_available()) else 'gloo')
     d = np.load(args.fixture)
     mld = MLDSystem([d['A'], d['B']], [d['F'], d['G'], d['h']], int(d['nub']))
-    ctrl = HybridModelPredictiveController(mld, int(d['T']), [d['Q'], d['R'], d['Q_T']], [d['F_T'], d['h_T']])
+    data = dict(T=int(d['T']), objective=[d['Q'], d['R'], d['Q_T']], terminal_set=[d['F_T'], d['h_T']])
+    if backend_factory is None:
+        ctrl = HybridModelPredictiveController(mld, data['T'], data['objective'], data['terminal_set'],
+                                               solver_params={'device': local if world > 1 else -1})
+    else:
+        class _Late(object):          # the controller wants a backend at construction; bind it right after
+            pass
+        ctrl = HybridModelPredictiveController(mld, data['T'], data['objective'], data['terminal_set'], backend=_Late())
+        ctrl.qp = backend_factory(ctrl.problem_data())
     bm = BatchedMPC(ctrl)
     os.makedirs(args.out, exist_ok=True)
     tag = 'sd_{:.3f}'.format(args.sd)
-    with open(os.path.join(args.out, 'solve_log_%s.log' % tag), 'w') as log:
+    seeds = tuple(range(rank, args.sims, world))           # this rank's simulations
+    log_name = 'solve_log_%s.log' % tag if world == 1 else 'solve_log_%s.rank%d.log' % (tag, rank)
+    with open(os.path.join(args.out, log_name), 'w') as log:
         log.write('Error standard deviation {:.3f}\n\n'.format(args.sd))
-        st = bm.closed_loop(np.array([0., 0., 1., 0.]), args.steps, e_sd=args.sd, seeds=tuple(range(args.sims)),
+        st = bm.closed_loop(np.array([0., 0., 1., 0.]), args.steps, e_sd=args.sd, seeds=seeds,
                             x_max=d['x_max'], frontier_width=args.width, cold_too=not args.no_cold, log=log)
+    if world > 1:
+        # per-simulation lists back into global simulation order; counters summed; wall = slowest rank
+        parts = [None] * world
+        dist.all_gather_object(parts, {k: st[k] for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'costs', 'cost_mismatches', 'steps', 'wall')})
+        merged = {k: [None] * args.sims for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'costs')}
+        for r, part in enumerate(parts):
+            for j, sim in enumerate(range(r, args.sims, world)):
+                for k in merged:
+                    merged[k][sim] = part[k][j]
+        st = dict(merged, cost_mismatches=sum((p['cost_mismatches'] for p in parts), []), steps=sum(p['steps'] for p in parts),
+                  wall=max(p['wall'] for p in parts))
+        st['steps_per_sec'] = st['steps'] / st['wall'] if st['wall'] > 0 else 0.
+        if rank != 0:
+            return 0
     full = [k for k in range(args.sims) if len(st['nodes_ws'][k]) == args.steps and len(st['costs'][k]) == args.steps]
     for key in ('nodes_ws', 'nodes_cs', 'len_ws'):
         rows = [st[key][k] for k in full if len(st[key][k]) == args.steps]
