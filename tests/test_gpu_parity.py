@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): statuses and binary assignments bit-exact, conti
 trajectories within 1e-5 relative.  Non-unique parts of a relaxation (inputs that no cost term
 sees, multipliers on degenerate faces) are compared through what they determine: objective,
 state trajectory, certificate residuals."""
+import os
+
 import numpy as np
 import pytest
 
@@ -16,12 +18,11 @@ pytestmark = pytest.mark.gpu
 X0 = np.array([0., 0., 1., 0.])
 RTOL = 1e-5   # north_star: continuous trajectories within 1e-5 relative
 # Nodes with (nearly) all binaries fixed have no interior: the big-M rows collapse into implied
-# equalities, the late interior-point systems are ill conditioned, and two roundings of the same
-# algorithm (oracle, 1/2/4 waves, generic kernel) can stop on iterates that differ by a few 1e-5 in
-# x although objective and residuals agree to 1e-7 (the stage cost's curvature is 1.7e-4 after
-# scaling: a 5e-9 dual residual is worth 3e-5 in x).  Gurobi's own 1e-6 tolerances leave ~1e-4
-# there.  Such nodes are compared at RTOL_DEGENERATE.
-RTOL_DEGENERATE = 2e-4
+# equalities and the late interior-point systems are ill conditioned.  Earlier kernels needed 2e-4 on
+# such nodes; with the substitution-form factor and two refinement steps the one tolerance holds
+# everywhere (tests/gpu_parity_stats.py: 4096-node frontiers agree with the oracle to 4e-10 in x, in
+# iteration counts on every node).  HMPC_TEST_RTOL_DEGENERATE loosens it for experiments.
+RTOL_DEGENERATE = float(os.environ.get('HMPC_TEST_RTOL_DEGENERATE', RTOL))
 
 
 def _traj_tol(fix):
