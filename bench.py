@@ -250,6 +250,12 @@ def main():
                          'algorithmic_bytes_per_launch': bytes_per_qp * B,
                          'algorithmic_bytes_per_qp': bytes_per_qp, 'kernel': 'hmpc_qp_kernel',
                          'kernel_ms_avg': kernel_ms, 'grid': grid, 'lds_bytes_per_wg': lds},
+            # secondary: algorithmic flops (per interior-point iteration T (7/3) (nx+nu)^3 + 2 nnz(A_c) (nx+nu)
+            # = 1.2e5 for this workload) against the f64 vector peak (half of MI355X_MICROARCH.md's 157.3 TFLOP/s FP32)
+            'flops': {'per_iteration': 1.2e5, 'iterations_per_qp': float(iters.mean()),
+                      'achieved_TFLOPs': 1.2e5 * float(iters.mean()) * B / (kernel_ms * 1e-3) / 1e12, 'peak_TFLOPs_f64_vector': 78.6,
+                      'frac': 1.2e5 * float(iters.mean()) * B / (kernel_ms * 1e-3) / 1e12 / 78.6,
+                      'note': 'neither bandwidth nor flops bound: sequential stage recursions, one wave per SIMD (DESIGN.md 5)'},
             'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
                       'not_converged': int((status > 1).sum()), 'ipm_iters_mean': float(iters.mean())},
         }
