@@ -213,7 +213,10 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         for (int j = 0; j < nu && same; j++) same = q->G_Tm1[r * nu + j] == q->G[r * nu + j];
         if (!same) { hmpc_destroy(h); return fail(HMPC_EINVAL, "the first nc rows of F_Tm1, G_Tm1, h_Tm1 must equal F, G, h"); }
     }
-    std::vector<double> Ct((size_t)(p.nT > 0 ? p.nT : 1) * nz, 0.0), ht(p.nT > 0 ? p.nT : 1, 0.0), sct(p.nT > 0 ? p.nT : 1, 1.0);
+    // padded to a whole number of 256-row tiles (zero rows): a lane of the last row slot that has no terminal row
+    // still addresses memory of these arrays
+    const size_t nTpad = ((size_t)p.nT + 255) / 256 * 256 + 256;
+    std::vector<double> Ct(nTpad * nz, 0.0), ht(nTpad, 0.0), sct(nTpad, 1.0);
     for (int k = 0; k < p.nT; k++) {
         const int r = q->nc + k;
         double n2 = 0;
