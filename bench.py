@@ -146,6 +146,9 @@ def main():
     ap.add_argument('--frontier', type=int, default=4096, help='nodes per GPU per step')
     ap.add_argument('--p-one', type=float, default=0.5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='N > 1 ranks all on cuda:0 with a gloo group: rehearses the multi-rank path on a one-GPU box '
+                         '(the number it prints is not a scaling measurement)')
     args = ap.parse_args()
 
     import torch
@@ -160,11 +163,16 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     ctrl = make_controller('cart_pole_with_walls', backend='hip', device=local)
     T, nub = ctrl.T, ctrl.mld.nub
@@ -238,7 +246,8 @@ def main():
         line = {
             'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier',
             'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak' if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'cart_pole_with_walls N=20, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), '
                                    'p_one=%.2f' % args.p_one,
