@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import conftest  # noqa
 import numpy as np
+import warm_start_hmpc_amd.qp_backend as qb
+if os.environ.get('HMPC_LIB'):
+    qb.LIBRARY_PATH = qb.LIBRARY_PATH.replace('libhmpc.so', os.environ['HMPC_LIB'])
 from helpers import make_controller, random_prefix_frontier
 T = int(os.environ.get('DBG_T', 20))
 name = os.environ.get('DBG_FIXTURE', 'cart_pole_with_walls')
