@@ -1,0 +1,32 @@
+"""Large randomized GPU <-> oracle sweep (diagnostic): many frontiers, random per-node initial states."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import conftest  # noqa
+import numpy as np
+from helpers import make_controller, random_prefix_frontier
+T = 20
+hip = make_controller('cart_pole_with_walls', T=T, backend='hip')
+orc = make_controller('cart_pole_with_walls', T=T, backend='oracle', threads=16)
+rng = np.random.default_rng(123)
+tot = bad_status = 0
+worst = 0.
+nbig = 0
+for rep in range(int(os.environ.get('DBG_REPS', 24))):
+    B = int(rng.choice([64, 300, 700, 2048, 4096]))
+    p_one = float(rng.choice([0.02, 0.1, 0.3, 0.5]))
+    fix = random_prefix_frontier(T, 4, B, p_one=p_one, seed0=100000 + 5000 * rep)
+    x0 = rng.uniform(-1, 1, (B, 4)) * np.array([.3, .2, 1.0, .8])
+    a, b = hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix)
+    tot += B
+    ns = int((a['status'] != b['status']).sum())
+    bad_status += ns
+    fin = (a['status'] == 0) & (b['status'] == 0)
+    if fin.any():
+        xa, xb = a['primal'][fin][:, :(T + 1) * 4], b['primal'][fin][:, :(T + 1) * 4]
+        dev = np.max(np.abs(xa - xb), axis=1) / np.maximum(1e-2, np.max(np.abs(xb), axis=1))
+        worst = max(worst, float(dev.max()))
+        nbig += int((dev > 1e-5).sum())
+    print('rep %2d B %4d p %.2f: status mismatches %d, not converged hip %d oracle %d, feasible %d, worst dev so far %.1e, > 1e-5: %d'
+          % (rep, B, p_one, ns, int((a['status'] > 1).sum()), int((b['status'] > 1).sum()), int(fin.sum()), worst, nbig), flush=True)
+print('TOTAL nodes %d, status mismatches %d, worst trajectory deviation %.2e, nodes above 1e-5: %d' % (tot, bad_status, worst, nbig))
