@@ -46,6 +46,8 @@ extern "C" {
 #define HMPC_MAXITER 2   /* not converged: the caller must not use the record */
 #define HMPC_NUMERICAL 3 /* numerical breakdown: idem */
 
+#define HMPC_ITERS_POLISHED 0x10000 /* flag in hmpc_result.iters */
+
 /* return codes */
 #define HMPC_OK 0
 #define HMPC_EINVAL -1 /* bad argument (sizes, null pointers) */
@@ -78,6 +80,12 @@ typedef struct hmpc_options {
     int32_t lazy_terminal; /* 1: try each node without the terminal-set rows first          */
     int32_t refine;        /* 1: one step of iterative refinement per Newton direction      */
     int32_t device;        /* HIP device ordinal, -1 = current                              */
+    int32_t polish;        /* 1: active-set polish -- an optimal node returns the vertex     */
+                           /*    solution of its active set (what Gurobi's simplex/crossover */
+                           /*    returns, bounded_qp.py:208), exactly complementary          */
+    int32_t reserved;      /* 0                                                             */
+    double polish_tol;     /* the polish is tried once residuals and gap are below this     */
+                           /*    (default 1e-4; it is accepted only if it verifies)          */
 } hmpc_options;
 
 /* Structure-of-arrays result of a batch of B nodes.  Any pointer may be NULL (not wanted).
@@ -91,7 +99,9 @@ typedef struct hmpc_result {
     double *obj;      /* B : primal objective, +inf if infeasible (bounded_qp.py:292-311)      */
     double *dual_obj; /* B : dual objective / Farkas objective   (bounded_qp.py:313-332)      */
     int32_t *status;  /* B                                                                    */
-    int32_t *iters;   /* B : interior-point iterations spent on the node                      */
+    int32_t *iters;   /* B : interior-point iterations spent on the node (low 16 bits);       */
+                      /*     bit 16 (HMPC_ITERS_POLISHED): the record is the polished vertex    */
+                      /*     solution (exactly complementary), not the interior-point iterate   */
     double *primal;   /* B x n_primal                                                         */
     double *dual;     /* B x n_dual                                                           */
 } hmpc_result;

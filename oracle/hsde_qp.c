@@ -404,9 +404,112 @@ static void kkt_residual(const prob_t *p, const work_t *k, const int8_t *fix, co
 
 static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i < n; i++) if (fabs(v[i]) > m) m = fabs(v[i]); return m; }
 
+
+/* ---- Active-set polish ---------------------------------------------------------------------------
+ * An interior-point iterate that meets the stopping test still carries, on nodes without an interior
+ * (big-M rows that collapse to equalities), an error of (dual residual) / (curvature of the stage cost)
+ * ~ 1e-5 in the trajectory.  What a simplex / crossover code -- the reference's Gurobi -- returns is the
+ * vertex solution of the optimal active set; this step computes that point from the iterate.
+ *
+ * Rows with z > s are taken as active.  The equality-constrained QP on them is solved by the method of
+ * multipliers with the same Riccati machinery (one factorisation, a few solves):
+ *     w+ = argmin 1/2 w'Pw + z'(C_A w - h_A) + rho/2 |C_A w - h_A|^2 + delta/2 |C_I (w - w0)|^2   s.t. dynamics, x_0, fixed binaries
+ *     z+ = z + rho (C_A w+ - h_A)
+ * i.e. one KKT solve with D = rho on the active rows, D = delta on the inactive ones (a proximal term in
+ * the metric of the inactive rows: it makes the step unique where the cost sees no input, and leaves the
+ * iterate's component there untouched), right-hand side rhs_c = h - z/rho (active), C w0 (inactive).
+ * Dependent active rows (the pairs f <= 0, -f <= 0) are harmless: the multipliers converge on the range of C_A.
+ * The result is exactly complementary (s_A = 0, z_I = 0) and exactly stationary; it is accepted only if
+ * z_A >= 0 and C_I w <= h_I hold to the tolerances below and the active rows are met to 1e-11 -- otherwise
+ * the interior-point iteration simply goes on (nothing of its state is touched).
+ * Outputs (tau = 1 units): k->w1, lam1, nuf1 and the row multipliers in k->dza.
+ */
+#define POLISH_RHO 1e5      /* penalty of the active rows (scaled problem: unit rows, largest Hessian entry 1) */
+#define POLISH_DELTA 1e-10 /* proximal weight of the inactive rows; must stay above eps * rho            */
+#define POLISH_ITERS 5      /* multiplier steps per active set                                            */
+#define POLISH_ROUNDS 10    /* active sets tried per attempt                                              */
+static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf)
+{
+    int nz = p->nz, T = p->T;
+    double *zk = k->dza, *cw = k->dsa, *cw0 = k->ec;
+    for (int t = 0; t < T; t++) {
+        const double *C = Ct(p, t); int m = mt(p, t), ro = p->roff[t];
+        for (int r = 0; r < m; r++) {
+            int q = ro + r;
+            if (!k->act[q]) { k->D[q] = 0; zk[q] = 0; cw0[q] = 0; continue; }
+            double a = 0;
+            for (int j = 0; j < nz; j++) a += C[r * nz + j] * k->w[t * nz + j];
+            cw0[q] = a / tau;
+            if (k->z[q] > k->s[q]) { k->D[q] = POLISH_RHO; zk[q] = k->z[q] / tau; }
+            else { k->D[q] = POLISH_DELTA; zk[q] = 0; }
+        }
+    }
+    const double ez = 1e-9 * (1 + zinf), es = 1e-9 * (1 + winf);
+    for (int round = 0; round < POLISH_ROUNDS; round++) {
+        if (factor(p, k, fix) != 0) { return 0; }
+        memcpy(cw, cw0, sizeof(double) * p->M); /* the proximal centre starts at the interior-point iterate */
+        double pinf = 0, pmove = 0;
+        for (int it = 0; it < POLISH_ITERS; it++) {
+            for (int t = 0; t < T; t++) {
+                const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+                for (int r = 0; r < m; r++) { int q = ro + r; k->rhs_c[q] = k->D[q] == POLISH_RHO ? hh[r] - zk[q] / POLISH_RHO : cw[q]; }
+            }
+            kkt_solve(p, k, fix, NULL, x0, NULL, 1, k->rhs_c, k->w1, k->lam1, k->nuf1, k->z1);
+            pinf = 0; pmove = 0;
+            for (int t = 0; t < T; t++) {
+                const double *C = Ct(p, t); int m = mt(p, t), ro = p->roff[t];
+                for (int r = 0; r < m; r++) {
+                    int q = ro + r;
+                    if (k->D[q] == POLISH_RHO) {
+                        double d = fabs(k->z1[q] - zk[q]) / POLISH_RHO;
+                        if (d > pinf) pinf = d;
+                        zk[q] = k->z1[q];
+                    } else if (k->act[q]) { /* the proximal centre follows the iterate */
+                        double a = 0;
+                        for (int j = 0; j < nz; j++) a += C[r * nz + j] * k->w1[t * nz + j];
+                        if (fabs(a - cw[q]) > pmove) pmove = fabs(a - cw[q]);
+                        cw[q] = a;
+                    }
+                }
+            }
+            if (it >= 1 && pinf <= 1e-12 * (1 + winf) && POLISH_DELTA * pmove <= 1e-13) break;
+        }
+        /* the active rows must be met, and the proximal term (dropped from the multipliers) must have died out:
+         * it is the stationarity residual of the result */
+        if (!(pinf <= 1e-10 * (1 + winf)) || !(POLISH_DELTA * pmove <= 1e-12 * (1 + zinf))) return 0;
+        /* Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides, but only those
+         * within a factor two of the worst violation / the most negative multiplier (a missing active row drags
+         * others across their bounds; the next round shows which of them are real). */
+        double vmax = 0, zmin = 0;
+        for (int t = 0; t < T; t++) {
+            const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+            for (int r = 0; r < m; r++) {
+                int q = ro + r;
+                if (!k->act[q]) continue;
+                if (k->D[q] == POLISH_RHO) { if (zk[q] < zmin) zmin = zk[q]; }
+                else if (cw[q] - hh[r] > vmax) vmax = cw[q] - hh[r];
+            }
+        }
+        if (vmax <= es && zmin >= -ez) {
+            for (int q = 0; q < p->M; q++) if (k->D[q] == POLISH_RHO && zk[q] < 0) zk[q] = 0;
+            return 1;
+        }
+        for (int t = 0; t < T; t++) {
+            const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
+            for (int r = 0; r < m; r++) {
+                int q = ro + r;
+                if (!k->act[q]) continue;
+                if (k->D[q] != POLISH_RHO) { if (vmax > es && cw[q] - hh[r] > 0.5 * vmax) { k->D[q] = POLISH_RHO; zk[q] = 0; } }
+                else if (zmin < -ez && zk[q] < 0.5 * zmin) { k->D[q] = POLISH_DELTA; zk[q] = 0; }
+            }
+        }
+    }
+    return 0;
+}
+
 /* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
-static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, double tol, double tol_inf, int max_iter,
-                     double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol)
+static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, int do_polish, double ptol, double tol, double tol_inf, int max_iter,
+                     double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol, int *polished_out)
 {
     int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
     int mact = 0;
@@ -427,7 +530,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
     for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
     for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
 
-    int status = ST_MAXITER, it = 0, extra_done = 0;
+    int status = ST_MAXITER, it = 0, extra_done = 0, polished = 0, npol = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
     double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
     double x0inf = vmaxabs(x0, nx);
@@ -490,14 +593,21 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         {
             const double gtol = tol * (1 + fmin(fabs(pobj), fabs(dob)));
             const int acceptable = rcinf / tau <= tol * (1 + winf + x0inf) && rdinf / tau <= tol * (1 + zinf) && gap <= gtol;
+            /* The polish is tried as soon as the iterate is good enough to read the active set from (ptol), once per
+             * iterate, and not on an iterate that is about to be undone. */
+            const double gptol = ptol * (1 + fmin(fabs(pobj), fabs(dob)));
+            /* the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex code's
+             * default): nothing more can be gained from the interior-point iteration on an interior-free node */
+            const int exhausted = status != ST_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * tol * (1 + winf + x0inf) &&
+                                  rdinf / tau <= 100 * tol * (1 + zinf) && gap <= 100 * gtol;
+            const int ready = do_polish && (acceptable || exhausted || (status != ST_OPTIMAL && rcinf / tau <= ptol * (1 + winf + x0inf) &&
+                                                                        rdinf / tau <= ptol * (1 + zinf) && gap <= gptol));
+            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf)) { status = ST_OPTIMAL; polished = npol; break; } }
             if (acceptable) {
                 status = ST_OPTIMAL;
                 if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tol * (1 + zinf)) || extra_done >= 3 || it == max_iter) break;
                 extra_done++;
-            } else if (status != ST_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * tol * (1 + winf + x0inf) &&
-                       rdinf / tau <= 100 * tol * (1 + zinf) && gap <= 100 * gtol) {
-                /* the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex
-                 * code's default): nothing more can be gained on an interior-free node */
+            } else if (exhausted) {
                 status = ST_OPTIMAL;
                 break;
             } else if (status == ST_OPTIMAL) {
@@ -515,9 +625,11 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      cert %.3e eta %.3e zinf %.3e raw rd %.3e rc %.3e\n", cert, eta, zinf * tau, rdinf, rcinf);
             /* (a) clean proof; (b) tau has collapsed against kappa: in exact arithmetic that alone
              * means "no optimum", and the proof is as accurate as double precision allows */
-            /* (c) tau has vanished (ten orders below kappa): the node is infeasible by less than any
-             * certificate can resolve in double precision; report it with the multipliers at hand */
-            if (eta > 0 && (cert <= tol_inf * eta || (tau <= 1e-8 * kap && cert <= 1e-3 * eta) || tau <= 1e-10 * kap)) { status = ST_INFEASIBLE; break; }
+            /* Every exit carries a bound on the certificate residual: a ray that is not a proof must not
+             * prune a subtree (a node whose tau vanishes without one ends MAXITER / NUMERICAL and is surfaced). */
+            if (eta > 0 && (cert <= tol_inf * eta || (tau <= 1e-8 * kap && cert <= 1e-3 * eta))) {
+                status = ST_INFEASIBLE; break;
+            }
         }
         if (it == max_iter) break;
 
@@ -616,6 +728,13 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         if (status == ST_OPTIMAL && it + 1 > max_iter) break;
     }
     *iters = it;
+    if (polished) { /* the polished point replaces the iterate (tau = 1 units; exactly complementary) */
+        memcpy(k->w, k->w1, sizeof(double) * n); memcpy(k->lam, k->lam1, sizeof(double) * (T + 1) * nx);
+        memcpy(k->nuf, k->nuf1, sizeof(double) * T * nub);
+        for (int r = 0; r < M; r++) k->z[r] = k->D[r] == POLISH_RHO ? k->dza[r] : 0.0;
+        tau = 1.0;
+    }
+    if (polished_out) *polished_out = polished;
 
     /* ---- outputs in the reference's conventions ---- */
     int nmu = (T - 1) * p->nc + p->ncL;
@@ -689,8 +808,8 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
                        const double *FL, const double *GL, const double *hL,
                        const double *Q, const double *R, const double *QT,
                        const double *x0, int x0_stride, int nbatch, const int8_t *fix,
-                       double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal, int refine,
-                       double *obj, double *dobj, int *status, int *iters, double *primal, double *dual)
+                       double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal, int refine, int do_polish, double ptol,
+                       double *obj, double *dobj, int *status, int *iters, double *primal, double *dual, int *polished)
 {
     if (nx + nu > 64 || nx > 32) return -1;
     prob_t *p = prob_create(nx, nu, nub, T, nc, ncL, nq, nr, nqT, A, B, F, G, h, FL, GL, hL, Q, R, QT);
@@ -710,13 +829,13 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
              * warm-start shift); an optimum that satisfies the masked rows strictly is the optimum
              * of the node.  Otherwise solve again with every row. */
             const double *xb = x0 + (size_t)b * x0_stride; const int8_t *fb = fix + (size_t)b * T * nub;
-            double *pb = primal + (size_t)b * np_, *db = dual + (size_t)b * nd, tv = 0; int it1 = 0, it2 = 0, st;
+            double *pb = primal + (size_t)b * np_, *db = dual + (size_t)b * nd, tv = 0; int it1 = 0, it2 = 0, st, pol = 0;
             if (ncL > nc && lazy_terminal) {
-                st = solve_one(p, k, xb, fb, 0, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
+                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
                 if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)))
-                    st = solve_one(p, k, xb, fb, 1, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv);
-            } else st = solve_one(p, k, xb, fb, 1, refine, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv);
-            status[b] = st; iters[b] = it1 + it2;
+                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
+            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+            status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol;
         }
         work_free(k);
     }

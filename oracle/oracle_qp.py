@@ -29,9 +29,9 @@ def _load():
     lib.oracle_solve_batch.restype = ctypes.c_int
     lib.oracle_solve_batch.argtypes = [ctypes.c_int] * 9 + [dp] * 11 + [dp, ctypes.c_int, ctypes.c_int,
                                                                        ctypes.POINTER(ctypes.c_int8),
-                                                                       ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                                       ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                                                        dp, dp, ctypes.POINTER(ctypes.c_int),
-                                                                       ctypes.POINTER(ctypes.c_int), dp, dp]
+                                                                       ctypes.POINTER(ctypes.c_int), dp, dp, ctypes.POINTER(ctypes.c_int)]
     return lib
 
 
@@ -42,7 +42,7 @@ def _d(a):
 class OracleBatchedQP(object):
     """CPU oracle behind the backend interface of the controller."""
 
-    def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, threads=1, lazy_terminal=True, refine=True):
+    def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, threads=1, lazy_terminal=True, refine=True, polish=True, polish_tol=1e-4):
         self.lib = _load()
         c = lambda M: np.ascontiguousarray(np.atleast_2d(M), dtype=np.float64)
         self.p = {k: (c(v) if k not in ('nx', 'nu', 'nub', 'T', 'h', 'h_Tm1') else v) for k, v in problem.items()}
@@ -51,6 +51,8 @@ class OracleBatchedQP(object):
         self.tol, self.tol_inf, self.max_iter, self.threads = tol, tol_inf, max_iter, threads
         self.lazy_terminal = int(lazy_terminal)
         self.refine = int(refine)
+        self.polish = int(polish)
+        self.polish_tol = float(polish_tol)
         p = self.p
         self.sizes = (p['nx'], p['nu'], p['nub'], p['T'], p['h'].size, p['h_Tm1'].size,
                       p['Q'].shape[0], p['R'].shape[0], p['Q_T'].shape[0])
@@ -66,15 +68,16 @@ class OracleBatchedQP(object):
         stride = 0 if x0.ndim == 1 else p['nx']
         out = dict(obj=np.empty(B), dual_obj=np.empty(B), status=np.empty(B, dtype=np.int32),
                    iters=np.empty(B, dtype=np.int32), primal=np.empty((B, self.n_primal)),
-                   dual=np.empty((B, self.n_dual)))
+                   dual=np.empty((B, self.n_dual)), polished=np.zeros(B, dtype=np.int32))
         tic = time.perf_counter()
         rc = self.lib.oracle_solve_batch(
             *self.sizes, _d(p['A']), _d(p['B']), _d(p['F']), _d(p['G']), _d(p['h']),
             _d(p['F_Tm1']), _d(p['G_Tm1']), _d(p['h_Tm1']), _d(p['Q']), _d(p['R']), _d(p['Q_T']),
             _d(x0), stride, B, fix.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
-            self.tol, self.tol_inf, self.max_iter, self.threads, self.lazy_terminal, self.refine,
+            self.tol, self.tol_inf, self.max_iter, self.threads, self.lazy_terminal, self.refine, self.polish, self.polish_tol,
             _d(out['obj']), _d(out['dual_obj']), out['status'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
-            out['iters'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _d(out['primal']), _d(out['dual']))
+            out['iters'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _d(out['primal']), _d(out['dual']),
+            out['polished'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
         if rc != 0:
             raise RuntimeError('oracle_solve_batch failed with code %d' % rc)
         out['time'] = time.perf_counter() - tic

@@ -1,11 +1,17 @@
 """Regenerates tests/golden/qp_golden.npz: input / expected-output vectors of the hot path.
 
 The reference stores no numeric solutions and its solver (Gurobi) is absent, so these vectors
-come from this repo's float64 CPU oracle (oracle/hsde_qp.c) and are accepted only after every
-one of them passed the reference's own certificate checks restated in tests/kkt_checks.py
-(KKT residuals / Farkas conditions below 1e-6).  They pin (a) the oracle against regressions and
-(b) the GPU path on the GPU box, where neither /root/reference nor this script's inputs beyond
-the fixtures exist.
+come from this repo's float64 CPU oracle (oracle/hsde_qp.c), run TIGHTER than the product
+(tol 1e-10, polish from a converged iterate: polish_tol 1e-8; the product runs tol 1e-8 /
+polish_tol 1e-4) and accepted only after every vector passed
+  * the reference's own certificate checks restated in tests/kkt_checks.py (KKT residuals /
+    Farkas conditions) at 1e-8 (optimal nodes: residuals, signs and duality gap against multipliers of
+    order 1e2 and forces of order 1e2; Farkas proofs at the solver's 1e-6), and
+  * for the optimal nodes, an independent dense active-set solve (tests/dense_qp.py, numpy SVD, no
+    code shared with the solver): state trajectories equal to 1e-7.
+They pin (a) the oracle against regressions and (b) the GPU path on the GPU box, where neither
+/root/reference nor this script's inputs beyond the fixtures exist.  Besides the node records the
+file holds the branch-and-bound incumbent of every case with its trajectory (x, uc).
 
     python tests/golden/make_golden_qp.py
 """
@@ -21,6 +27,7 @@ for p in (ROOT, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'), os.path.join(RO
 
 from helpers import make_controller, random_prefix_frontier  # noqa: E402
 from kkt_checks import check_solution  # noqa: E402
+from dense_qp import dense_qp, active_set_primal  # noqa: E402
 from warm_start_hmpc_amd.subproblem_solution import SubproblemSolution  # noqa: E402
 
 
@@ -28,25 +35,49 @@ def identifier_of(fix_row, nub):
     return {(k // nub, k % nub): float(v) for k, v in enumerate(fix_row) if v >= 0}
 
 
-def case(name, T, x0, fix, terminal=True, fixture='cart_pole_with_walls'):
-    ctrl = make_controller(fixture, T=T, terminal=terminal, backend='oracle')
+TIGHT = dict(tol=1e-10, polish_tol=1e-8, threads=8)
+
+
+def case(name, T, x0, fix, terminal=True, fixture='cart_pole_with_walls', bb=True):
+    ctrl = make_controller(fixture, T=T, terminal=terminal, backend='oracle', **TIGHT)
     res = ctrl.qp.solve_batch(x0, fix)
     assert np.all(res['status'] <= 1)
+    nx = ctrl.mld.nx
+    dq = dense_qp(ctrl)
+    worst = 0.
     for b in range(fix.shape[0]):
         sol = SubproblemSolution.from_rows(ctrl.layout, fix[b], res['obj'][b], res['dual_obj'][b], res['status'][b],
                                            res['primal'][b], res['dual'][b])
-        check_solution(ctrl, sol, identifier_of(fix[b], ctrl.mld.nub), x0, tol=1e-6)
-    nx = ctrl.mld.nx
+        xb = x0 if x0.ndim == 1 else x0[b]
+        kind = check_solution(ctrl, sol, identifier_of(fix[b], ctrl.mld.nub), xb, tol=1e-8 if res['status'][b] == 0 else 1e-6)
+        if kind == 'optimal':
+            assert res['polished'][b] > 0
+            w, resid = active_set_primal(ctrl, dq, xb, fix[b], res['dual'][b])
+            xs = res['primal'][b][:(T + 1) * nx]
+            err = np.max(np.abs(w[:(T + 1) * nx] - xs)) / max(1e-2, np.max(np.abs(xs)))
+            assert resid < 1e-10 and err < 1e-7, (name, b, resid, err)
+            worst = max(worst, err)
     out = {name + '_T': T, name + '_x0': x0, name + '_fix': fix, name + '_status': res['status'],
            name + '_obj': res['obj'], name + '_dual_obj': res['dual_obj'],
-           name + '_x': res['primal'][:, :(T + 1) * nx], name + '_terminal': terminal}
-    # branch and bound summary from the same state
+           name + '_x': res['primal'][:, :(T + 1) * nx], name + '_u': res['primal'][:, (T + 1) * nx:],
+           name + '_terminal': terminal}
+    if not bb:
+        print(name, 'nodes', fix.shape[0], 'optimal', int((res['status'] == 0).sum()), 'worst x vs dense active-set solve %.1e' % worst)
+        return out
+    # branch and bound from the same state: incumbent and its trajectory (path independent unless the MIQP has a
+    # tie) from the tight configuration; solve / leaf counts (they depend on the order in which equal bounds are
+    # met, i.e. on the last digits of the multipliers) from the product's configuration
     sol, leaves, solves, _ = ctrl.feedforward(x0, printing_period=None)
+    default = make_controller(fixture, T=T, terminal=terminal, backend='oracle', threads=8)
+    _, leaves, solves, _ = default.feedforward(x0, printing_period=None)
     out[name + '_bb_solves'] = solves
     out[name + '_bb_leaves'] = len(leaves)
     out[name + '_bb_cost'] = np.inf if sol is None else sol.objective
     out[name + '_bb_ub'] = np.zeros((T, ctrl.mld.nub)) if sol is None else np.array(sol.variables['ub'])
-    print(name, 'nodes', fix.shape[0], 'optimal', int((res['status'] == 0).sum()), 'B&B', solves, len(leaves), out[name + '_bb_cost'])
+    out[name + '_bb_x'] = np.zeros((T + 1, nx)) if sol is None else np.array(sol.variables['x'])
+    out[name + '_bb_uc'] = np.zeros((T, ctrl.mld.nu - ctrl.mld.nub)) if sol is None else np.array(sol.variables['uc'])
+    print(name, 'nodes', fix.shape[0], 'optimal', int((res['status'] == 0).sum()), 'worst x vs dense active-set solve %.1e' % worst,
+          'B&B', solves, len(leaves), out[name + '_bb_cost'])
     return out
 
 
@@ -61,6 +92,21 @@ if __name__ == '__main__':
     for k in range(20):
         f[k, :4 * (k + 1)] = best[:4 * (k + 1)]
     data.update(case('n20dive', 20, np.array([0., 0., 1., 0.]), f))
+    # every node a cold-started branch and bound solves from the reference's initial state (the nodes of a real
+    # tree: most binaries fixed, big-M rows collapsed into equalities -- the ill-conditioned ones), and its leaves
+    ctrl = make_controller('cart_pole_with_walls', T=20, backend='oracle', **TIGHT)
+    seen, inner = [], ctrl.solve_frontier
+
+    def recording(identifiers, x0):
+        seen.extend(ctrl._fix_vector(i) for i in identifiers)
+        return inner(identifiers, x0)
+    ctrl.solve_frontier = recording
+    _, leaves, solves, _ = ctrl.feedforward(np.array([0., 0., 1., 0.]), printing_period=None)
+    f = np.unique(np.array(seen + [ctrl._fix_vector(l.identifier) for l in leaves], dtype=np.int8), axis=0)
+    data.update(case('n20tree', 20, np.array([0., 0., 1., 0.]), f))
+    # one initial state per node
+    f = random_prefix_frontier(20, 4, 64, p_one=0.05, seed0=6000)
+    data.update(case('n20x0', 20, np.random.default_rng(5).uniform(-1, 1, (64, 4)) * np.array([.3, .1, .6, .4]), f, bb=False))
     f = random_prefix_frontier(10, 4, 24, p_one=0.1, seed0=2000)
     f[0, :] = -1
     data.update(case('n10', 10, np.array([0., 0., .5, 0.]), f))

@@ -90,3 +90,59 @@ def record_close(a, b, tol=1e-5):
     fin = np.isfinite(a['obj'])
     assert np.array_equal(fin, np.isfinite(b['obj']))
     np.testing.assert_allclose(a['obj'][fin], b['obj'][fin], rtol=tol, atol=tol * 1e-2)
+
+
+def exercise_bounded_qp(ctrl):
+    """The reference's one-node-at-a-time flow (controller.py:254-271 over bounded_qp.py:127-341) and the identities of
+    test_bounded_qp.py:104-189 (Farkas signs, dual objective = -sum rhs * multiplier, strong duality) on a controller
+    with T = 10 of the cart-pole-with-walls system, whatever its backend."""
+    import pytest
+    T, nub, nx = ctrl.T, ctrl.mld.nub, ctrl.mld.nx
+    qp = ctrl.bounded_qp()
+    with pytest.raises(RuntimeError, match='not solved'):
+        qp.primal_objective()
+    with pytest.raises(KeyError):
+        qp.add_variables(3, lb=[0.] * 3)
+    with pytest.raises(ValueError, match='right dimension'):
+        qp.set_constraint_rhs('lam_0', np.zeros(nx + 1))
+    with pytest.raises(ValueError, match='right dimension'):
+        qp.set_constraint_rhs('no_such_family', np.zeros(2))
+    assert qp.get_constraint_rhs('no_such_family').size == 0
+    x0 = np.array([0., 0., .5, 0.])
+    qp.set_constraint_rhs('lam_0', x0)
+    ctrl._set_bound_binaries({(0, 0): 0., (0, 1): 0., (0, 2): 1.}, qp)
+    np.testing.assert_array_equal(qp.get_constraint_rhs('nu_lb_0'), [-0., -0., -1., -0.])   # rhs of nu_lb is MINUS the bound
+    np.testing.assert_array_equal(qp.get_constraint_rhs('nu_ub_0'), [0., 0., 1., 1.])
+    np.testing.assert_array_equal(qp.get_constraint_rhs('mu_%d' % (T - 1)), ctrl.h_Tm1)
+
+    def farkas_cost(q):       # - sum over ALL constraints of rhs * multiplier (bounded_qp.py:313-332)
+        total = 0.
+        for t in range(T + 1):
+            total -= q.get_constraint_rhs('lam_%d' % t).dot(q.dual_optimizer('lam_%d' % t))
+        for t in range(T):
+            for fam in ('mu', 'nu_lb', 'nu_ub'):
+                total -= q.get_constraint_rhs('%s_%d' % (fam, t)).dot(q.dual_optimizer('%s_%d' % (fam, t)))
+        return total
+
+    qp.optimize()                                                    # this node is infeasible (binary 2 on at time 0)
+    assert np.isinf(qp.primal_objective()) and qp.primal_optimizer('x_1') is None
+    assert qp.dual_objective() > 0 and abs(qp.dual_objective() - farkas_cost(qp)) < 1e-9 * (1 + qp.dual_objective())
+    for t in range(T):
+        for fam in ('mu', 'nu_lb', 'nu_ub'):
+            assert np.all(qp.dual_optimizer('%s_%d' % (fam, t)) >= -1e-12)
+
+    ctrl._set_bound_binaries({(0, i): 0. for i in range(nub)}, qp)  # feasible node
+    with pytest.raises(RuntimeError, match='not solved'):          # editing a rhs invalidates the solution
+        qp.dual_objective()
+    qp.optimize()
+    sol, _ = ctrl._solve_subproblem({(0, i): 0. for i in range(nub)}, x0)
+    assert qp.primal_objective() == sol.primal.objective
+    np.testing.assert_array_equal(qp.primal_optimizer('x_3'), sol.primal.variables['x'][3])
+    np.testing.assert_array_equal(qp.dual_optimizer('mu_2'), sol.dual.variables['mu'][2])
+    assert abs(qp.dual_objective() - qp.primal_objective()) < 1e-7                               # strong duality
+    # dual objective of an optimal point from its multipliers: -1/4 (|rho|^2 + |sigma|^2) - sum rhs * multiplier
+    quad = sum(np.sum(r ** 2) for r in sol.dual.variables['rho']) + sum(np.sum(s ** 2) for s in sol.dual.variables['sigma'])
+    assert abs(-0.25 * quad + farkas_cost(qp) - qp.dual_objective()) < 1e-9
+    qp.set_constraint_rhs('nu_ub_1', [.5, 1., 1., 1.])
+    with pytest.raises(ValueError, match='free'):
+        qp.optimize()

@@ -131,21 +131,46 @@ def test_other_horizons_known_answers():
     assert sol is None and all(np.isinf(l.lb) for l in leaves)          # N=10 from x0=[0,0,1,0] is infeasible
     sol, leaves, solves, _ = c10.feedforward(np.array([0., 0., .5, 0.]), printing_period=None)
     assert abs(sol.objective - 0.0995300) < 1e-6 and np.all(np.array(sol.variables['ub']) == 0)
-    assert (solves, len(leaves)) == (80, 41)
+    assert abs(solves - 80) <= 2 and abs(len(leaves) - 41) <= 1     # (counts wobble with the last digits of the multipliers)
 
 
 def test_golden_vectors():
+    # the golden file comes from this oracle run tighter (tol 1e-10, polish from a converged iterate) and accepted
+    # against an independent dense solve; the default configuration -- the product's -- must reproduce it
     g = load_fixture('qp_golden')
-    for name, fixture in [('n20', 'cart_pole_with_walls'), ('n20dive', 'cart_pole_with_walls'),
-                          ('n10', 'cart_pole_with_walls'), ('onewall', 'cart_pole_one_wall')]:
+    for name, fixture in [('n20', 'cart_pole_with_walls'), ('n20dive', 'cart_pole_with_walls'), ('n20tree', 'cart_pole_with_walls'),
+                          ('n20x0', 'cart_pole_with_walls'), ('n10', 'cart_pole_with_walls'), ('onewall', 'cart_pole_one_wall')]:
         T = int(g[name + '_T'])
-        ctrl = make_controller(fixture, T=T, terminal=bool(g[name + '_terminal']), backend='oracle')
+        ctrl = make_controller(fixture, T=T, terminal=bool(g[name + '_terminal']), backend='oracle', threads=8)
         res = ctrl.qp.solve_batch(g[name + '_x0'], g[name + '_fix'])
         assert np.array_equal(res['status'], g[name + '_status'])
         fin = res['status'] == 0
-        np.testing.assert_allclose(res['obj'][fin], g[name + '_obj'][fin], rtol=1e-7, atol=1e-10)
+        assert np.all(res['polished'][fin] > 0)
+        np.testing.assert_allclose(res['obj'][fin], g[name + '_obj'][fin], rtol=1e-8, atol=1e-12)
         nx = ctrl.mld.nx
-        np.testing.assert_allclose(res['primal'][fin][:, :(T + 1) * nx], g[name + '_x'][fin], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(res['primal'][fin][:, :(T + 1) * nx], g[name + '_x'][fin], rtol=1e-6, atol=1e-7)
+
+
+def test_trajectories_against_dense_active_set_solve():
+    # independent of the Riccati / interior-point / polish code: the node QP as dense matrices, the active set read
+    # from the record's multipliers, numpy SVD (tests/dense_qp.py).  Nodes of a real tree (the ill-conditioned ones:
+    # without the polish the interior-point iterate is off by up to 4e-5 there) and random prefixes.
+    from dense_qp import dense_qp, active_set_primal
+    g = load_fixture('qp_golden')
+    ctrl = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
+    raw = make_controller('cart_pole_with_walls', backend='oracle', threads=8, polish=False)
+    dq = dense_qp(ctrl)
+    fix = g['n20tree_fix'][::3]
+    res, unp = ctrl.qp.solve_batch(X0, fix), raw.qp.solve_batch(X0, fix)
+    worst = worst_raw = 0.
+    for b in np.flatnonzero(res['status'] == 0):
+        w, resid = active_set_primal(ctrl, dq, X0, fix[b], res['dual'][b])
+        scale = max(1e-2, np.max(np.abs(w[:84])))
+        worst = max(worst, np.max(np.abs(w[:84] - res['primal'][b][:84])) / scale)
+        worst_raw = max(worst_raw, np.max(np.abs(w[:84] - unp['primal'][b][:84])) / scale)
+        assert resid < 1e-10
+    assert worst < 1e-7, worst
+    assert worst_raw < 1e-3          # (what the polish is for: measured 4e-5 on this set)
 
 
 def test_results_do_not_depend_on_batch_or_threads():
@@ -165,12 +190,12 @@ def test_speculative_expansion_changes_launches_not_results():
     base_stats, spec_stats = {}, {}
     sol0, leaves0, solves0, _ = ctrl.feedforward(x0, printing_period=None, stats=base_stats)
     sol1, leaves1, solves1, _ = ctrl.feedforward(x0, printing_period=None, speculation_depth=4, stats=spec_stats)
-    assert solves0 == solves1 == 80 and len(leaves0) == len(leaves1) == 41
+    assert solves0 == solves1 and abs(solves0 - 80) <= 2 and len(leaves0) == len(leaves1) == 41
     assert [sorted(l.identifier.items()) for l in leaves0] == [sorted(l.identifier.items()) for l in leaves1]
     assert [l.lb for l in leaves0] == [l.lb for l in leaves1]
     assert sol0.objective == sol1.objective
     assert np.array_equal(np.array(sol0.variables['ub']), np.array(sol1.variables['ub']))
-    assert base_stats['rounds'] == 80 and base_stats['speculative'] == 0
+    assert base_stats['rounds'] == solves0 and base_stats['speculative'] == 0
     assert spec_stats['rounds'] < 30
     assert spec_stats['launched'] >= solves1 and spec_stats['wasted'] == spec_stats['launched'] - solves1
     # warm-started step: one stage of new binaries, the dive collapses into a couple of launches

@@ -181,6 +181,8 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     p.max_iter = opt && opt->max_iter > 0 ? opt->max_iter : 100;
     p.lazy = opt ? opt->lazy_terminal : 1;
     p.refine = opt ? opt->refine : 1;
+    p.polish = opt ? opt->polish : 1;
+    p.ptol = opt && opt->polish_tol > 0 ? opt->polish_tol : 1e-4;
 
     StageHost reg;
     build_stage(*q, q->F, q->G, q->h, q->nc, reg);

@@ -43,6 +43,8 @@ struct DevProb {
     double cs;                                 // cost scale
     double tol, tol_inf;
     int max_iter, lazy, refine;
+    int polish;                                // active-set polish of optimal iterates (hmpc_options.polish)
+    double ptol;                               //   tried once the scaled residuals and gap are below ptol
 };
 
 struct DevOut {
@@ -59,7 +61,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
     const size_t n = p.n, T = p.T, nx = p.nx, nu = p.nu, nz = p.nz, nub = p.nub, M = p.M;
     size_t d = 0, i = 0, b = 0;
     const size_t nxs = nx * (nx + 1) / 2, lms = nx * nu + nu * (nu - 1) / 2;
-    const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
+    const size_t dir = n + (T + 1) * nx + T * nub, fscr = nz * nz + (kc > 0 ? nz * nz : nx * nz);
     d += dir;                                                             // w lam nuf
     d += M;                                                               // e (row vector: z / D / D.*rhs / dz in turn)
     d += T * nu + (big ? 0 : T * lms + (T + 1) * nxs);                    // dinv ; Lm Pr (global slab if big)

@@ -37,6 +37,12 @@
 #include "hmpc_device.h"
 
 #define WAVE 64
+// active-set polish (same constants as oracle/hsde_qp.c): penalty of the active rows, proximal weight of the
+// inactive rows (must stay above eps * rho), multiplier steps per active set, active sets per attempt
+#define HMPC_POLISH_RHO 1e5
+#define HMPC_POLISH_DELTA 1e-10
+#define HMPC_POLISH_ITERS 5
+#define HMPC_POLISH_ROUNDS 10
 #ifndef HMPC_KERNEL_ATTR
 #define HMPC_KERNEL_ATTR
 #endif
@@ -1256,7 +1262,7 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 // Returns status; tau and the iteration count through references.
 template <class D, int RS, class RM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  double *trace)
+                  bool &polished_out, double *trace)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -1281,12 +1287,20 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     x0inf = block_max<D>(x0inf, S.red, lane);
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
+    polished_out = false;
+    bool tried = false; // the polish has been tried (and failed) on the current iterate
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
 #ifdef HMPC_STAMPS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
     long long facc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (it = 0; it <= p.max_iter; it++) {
+    // One loop runs the interior-point iterations (mode 0) and the passes of the ACTIVE-SET POLISH (mode 1: a new
+    // active set, with factorisation; mode 2: a further multiplier step with the factorisation at hand): the
+    // polish reuses the factorisation and the constant-direction solve below instead of owning copies of them.
+    int mode = 0, round = 0, al = 0;
+    double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
+    for (it = 0; it <= p.max_iter;) {
+      if (mode == 0) {
         STAMP(7);
         LANE_OPAQUE(lane);
         // ---------------- residuals ----------------
@@ -1294,7 +1308,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             S.e[rw.e] = R.z(k, rw.e); // S.e <- z for the C'z products below
         ROWS_END
         __syncthreads();
-        double wPw = 0;
+        wPw = 0;
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
             const int i = o - t * nz, dim = t < T ? nz : nx;
@@ -1303,7 +1317,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             for (int j = 0; j < dim; j++) a += PP[i * dim + j] * S.w[t * nz + j];
             wPw += a * S.w[o];
         }
-        double rdinf = 0, certinf = 0, fy = 0, winf = 0, yinf = 0;
+        double rdinf = 0, certinf = 0, fy = 0, yinf = 0;
+        winf = 0;
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
             const int j = o - t * nz;
@@ -1336,7 +1351,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             S.rdyn[o] = a;
             rcinf = fmax(rcinf, fabs(a));
         }
-        double hz = 0, sz = 0, zinf = 0;
+        double hz = 0, sz = 0;
+        zinf = 0;
         ROWS_BEGIN(k, rw)
             double a = 0;
             if (rm.active(p, S, k, rw)) {
@@ -1360,8 +1376,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             block_reduce<D, 9>(v, op, S.red, lane);
             rdinf = v[0]; certinf = v[1]; winf = v[2]; rcinf = v[3]; zinf = v[4]; fy = v[5]; hz = v[6]; sz = v[7]; wPw = v[8];
         }
-        const double rg = wPw / tau + fy + hz + kap;
-        const double mu = (sz + tau * kap) / (mact + 1);
+        rg = wPw / tau + fy + hz + kap;
+        mu = (sz + tau * kap) / (mact + 1);
         STAMP(0);
 
         // ---------------- termination ----------------
@@ -1378,18 +1394,28 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         // acceptable iterate exists, up to 3 more iterations are spent on the desired level; if one of
         // them is worse (precision floor of the linear algebra) it is undone -- the direction is still
         // in place -- and the acceptable iterate returned.
+        bool polish = false;
         {
             const double gtol = p.tol * (1 + fmin(fabs(pobj), fabs(dob)));
             const bool acceptable = rcinf / tau <= p.tol * (1 + winf / tau + x0inf) &&
                                     rdinf / tau <= p.tol * (1 + zinf / tau) && gap <= gtol;
-            if (acceptable) {
+            // The polish (below) is tried as soon as the iterate is good enough to read the active set from
+            // (ptol), once per iterate, and not on an iterate that is about to be undone.
+            const double gptol = p.ptol * (1 + fmin(fabs(pobj), fabs(dob)));
+            // the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex code's
+            // default): nothing more can be gained from the interior-point iteration on an interior-free node
+            const bool exhausted = status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
+                                   rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol;
+            polish = p.polish && !tried &&
+                     (acceptable || exhausted || (status != HMPC_OPTIMAL && rcinf / tau <= p.ptol * (1 + winf / tau + x0inf) &&
+                                                  rdinf / tau <= p.ptol * (1 + zinf / tau) && gap <= gptol));
+            if (polish) {
+                // decided by the passes of the polish
+            } else if (acceptable) {
                 status = HMPC_OPTIMAL;
                 if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * p.tol * (1 + zinf / tau)) || extra_done >= 3 || it == p.max_iter) break;
                 extra_done++;
-            } else if (status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
-                       rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol) {
-                // the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex
-                // code's default): nothing more can be gained on an interior-free node
+            } else if (exhausted) {
                 status = HMPC_OPTIMAL;
                 break;
             } else if (status == HMPC_OPTIMAL) {
@@ -1408,43 +1434,184 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 break;
             }
         }
-        // third clause: tau has vanished (ten orders below kappa) -- infeasible by less than a certificate
-        // can resolve in double precision; reported with the multipliers at hand
-        if (eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta) || tau <= 1e-10 * kap)) {
+        // Every infeasibility exit carries a bound on the certificate residual: a ray that is not a proof must
+        // not prune a subtree (a node whose tau vanishes without one ends MAXITER / NUMERICAL and is surfaced).
+        if (!polish && eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
             status = HMPC_INFEASIBLE;
             break;
         }
-        if (it == p.max_iter) break;
+        if (!polish && it == p.max_iter) break;
 
-        // ---------------- factorisation ----------------
+        // ---------------- barrier weights / active set ----------------
+        // ACTIVE-SET POLISH: the vertex solution of the active set read from the iterate -- what a simplex /
+        // crossover code returns; an interior-point iterate that meets the stopping test still carries
+        // (dual residual) / (curvature of the stage cost) ~ 1e-5 in the trajectory on nodes without an interior.
+        // Rows with z > s are taken as active; the equality-constrained QP on them is solved by the method of
+        // multipliers with the machinery at hand -- D = rho on the active rows, D = delta on the others (a
+        // proximal term in the metric of the inactive rows: unique step where the cost sees no input), one
+        // factorisation per active set and a few solves with the right-hand side of the constant direction
+        // shifted by the multipliers:  e = rho h - z (active), delta C w_c (inactive; w_c the proximal centre,
+        // which follows the iterate).  Rows that end on the wrong side (negative multiplier / violated) change
+        // sides and a new round starts.  The result is exactly complementary and stationary and is taken only
+        // if it verifies; otherwise the iteration goes on from the untouched iterate.  Same steps, constants
+        // and tolerances as oracle/hsde_qp.c polish().
         LANE_OPAQUE(lane);
         __syncthreads(); // every thread is done reading z from S.e
-        ROWS_BEGIN(k, rw)
-            const double zr = R.z(k, rw.e); // zero on inactive rows
-            const double d = zr != 0.0 ? zr * frcp(R.s(k, rw.e)) : 0.0;
-            R.D(k, rw.e) = d; // the slot holds D from here to the update of this iteration
-            S.e[rw.e] = d;    // S.e <- D for the Gram phase of the factorisation
-        ROWS_END
+        if (polish) {
+            ROWS_BEGIN(k, rw)
+                const double zr = R.z(k, rw.e); // zero on rows that take no part in this solve
+                double d = 0.0;
+                if (zr != 0.0) {
+                    R.prod(k, rw.e) = zr; // kept for the way back
+                    if (zr > R.s(k, rw.e)) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
+                    else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
+                    R.D(k, rw.e) = d;
+                }
+                S.e[rw.e] = d;
+            ROWS_END
+            mode = 1; round = 0; al = 0;
+        } else {
+            ROWS_BEGIN(k, rw)
+                const double zr = R.z(k, rw.e); // zero on inactive rows
+                const double d = zr != 0.0 ? zr * frcp(R.s(k, rw.e)) : 0.0;
+                R.D(k, rw.e) = d; // the slot holds D from here to the update of this iteration
+                S.e[rw.e] = d;    // S.e <- D for the Gram phase of the factorisation
+            ROWS_END
+        }
         __syncthreads();
         STAMP(1);
-        int frc;
-        if constexpr (D::kNX > 0) frc = factor_reg<D>(p, S, lane FSTAMP_PASS);
-        else frc = factor<D>(p, S, lane);
-        if (frc != 0) {
-            ROWS_BEGIN(k, rw)
-                R.z(k, rw.e) = R.D(k, rw.e) * R.s(k, rw.e); // the slots hold z again
-            ROWS_END
-            if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL;
-            break;
-        }
-        STAMP(2);
-        ROWS_BEGIN(k, rw)
-            S.e[rw.e] = R.D(k, rw.e) * rm.h(p, S, k, rw); // right-hand side of the constant direction
-        ROWS_END
-        __syncthreads();
+      } // mode == 0
 
-        // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-        kkt_dispatch<D, RS>(p, S, R, rm, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+        // ---------------- factorisation ----------------
+        if (mode != 2) {
+            int frc;
+            if constexpr (D::kNX > 0) frc = factor_reg<D>(p, S, lane FSTAMP_PASS);
+            else frc = factor<D>(p, S, lane);
+            STAMP(2);
+            if (frc != 0) {
+                if (mode == 0) {
+                    ROWS_BEGIN(k, rw)
+                        R.z(k, rw.e) = R.D(k, rw.e) * R.s(k, rw.e); // the slots hold z again
+                    ROWS_END
+                    if (status != HMPC_OPTIMAL) status = HMPC_NUMERICAL;
+                    break;
+                }
+                mode = 3; // the polish gives up
+            } else if (mode == 1) {
+                // the solves consume the factorisation's mb in S.g: keep a copy (S.rd is recomputed anyway)
+                for (int o = lane; o < T * nz; o += D::kNT) S.rd[o] = S.g[o];
+            }
+        }
+        if (mode != 3) {
+            LANE_OPAQUE(lane);
+            ROWS_BEGIN(k, rw)
+                const double d = R.D(k, rw.e);
+                double v = d * rm.h(p, S, k, rw); // right-hand side of the constant direction
+                if (mode != 0) v = d == HMPC_POLISH_RHO ? v - R.dz(k, rw.e) : d * R.dz(k, rw.e);
+                S.e[rw.e] = v;
+            ROWS_END
+            if (mode == 2)
+                for (int o = lane; o < T * nz; o += D::kNT) S.g[o] = S.rd[o];
+            __syncthreads();
+
+            // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
+            kkt_dispatch<D, RS>(p, S, R, rm, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+        }
+        if (mode != 0) {
+            // ---------------- polish: multiplier step, verification, next pass ----------------
+            int outcome = 0; // 0 give up, 1 verified, 2 next pass
+            if (mode != 3) {
+                double pinf = 0, pmove = 0;
+                ROWS_BEGIN(k, rw)
+                    const double d = R.D(k, rw.e);
+                    if (d == HMPC_POLISH_RHO) { // multiplier step
+                        const double zn = S.e[rw.e];
+                        pinf = fmax(pinf, fabs(zn - R.dz(k, rw.e)));
+                        R.dz(k, rw.e) = zn;
+                    } else if (d != 0.0) { // the proximal centre follows the iterate
+                        const double a = rm.dot(p, S, k, rw, S.w1);
+                        pmove = fmax(pmove, fabs(a - R.dz(k, rw.e)));
+                        R.dz(k, rw.e) = a;
+                    }
+                ROWS_END
+                {
+                    double v[2] = {pinf, pmove};
+                    const int op[2] = {1, 1};
+                    block_reduce<D, 2>(v, op, S.red, lane);
+                    pinf = v[0] / HMPC_POLISH_RHO; pmove = v[1];
+                }
+                if (!((al >= 1 && pinf <= 1e-12 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-13) || al == HMPC_POLISH_ITERS - 1)) {
+                    al++;
+                    mode = 2;
+                    outcome = 2;
+                } else if (pinf <= 1e-10 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-12 * (1 + zinf / tau)) {
+                    // (otherwise give up: the active rows are not met, or the proximal term -- dropped from the
+                    // multipliers, hence the stationarity residual of the result -- has not died out)
+                    // Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides,
+                    // but only those within a factor two of the worst violation / the most negative multiplier (a
+                    // missing active row drags others across their bounds; the next round shows which are real).
+                    const double ez = 1e-9 * (1 + zinf / tau), es = 1e-9 * (1 + winf / tau);
+                    double vmax = 0, zmin = 0;
+                    ROWS_BEGIN(k, rw)
+                        const double d = R.D(k, rw.e);
+                        if (d == HMPC_POLISH_RHO) zmin = fmin(zmin, R.dz(k, rw.e));
+                        else if (d != 0.0) vmax = fmax(vmax, R.dz(k, rw.e) - rm.h(p, S, k, rw));
+                    ROWS_END
+                    {
+                        double v[2] = {vmax, zmin};
+                        const int op[2] = {1, 2};
+                        block_reduce<D, 2>(v, op, S.red, lane);
+                        vmax = v[0]; zmin = v[1];
+                    }
+                    if (vmax <= es && zmin >= -ez) {
+                        outcome = 1;
+                    } else if (++round < HMPC_POLISH_ROUNDS) {
+                        ROWS_BEGIN(k, rw)
+                            double d = R.D(k, rw.e);
+                            if (d != 0.0) {
+                                if (d != HMPC_POLISH_RHO) {
+                                    if (vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = 0.0; }
+                                } else if (zmin < -ez && R.dz(k, rw.e) < 0.5 * zmin) {
+                                    d = HMPC_POLISH_DELTA;
+                                }
+                                R.D(k, rw.e) = d;
+                                // next active set: the proximal centre starts at the interior-point iterate again
+                                if (d == HMPC_POLISH_DELTA) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
+                            }
+                            S.e[rw.e] = d;
+                        ROWS_END
+                        __syncthreads();
+                        al = 0;
+                        mode = 1;
+                        outcome = 2;
+                    }
+                }
+            }
+            if (outcome == 2) continue;
+            if (outcome == 1) { // the polished point replaces the iterate (tau = 1 units)
+                for (int o = lane; o < n; o += D::kNT) S.w[o] = S.w1[o];
+                for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] = S.lam1[o];
+                for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] = S.nuf1[o];
+                ROWS_BEGIN(k, rw)
+                    const double d = R.D(k, rw.e);
+                    if (d != 0.0) R.z(k, rw.e) = d == HMPC_POLISH_RHO ? fmax(R.dz(k, rw.e), 0.0) : 0.0;
+                ROWS_END
+                tau = 1.0;
+                status = HMPC_OPTIMAL;
+                polished_out = true;
+                __syncthreads();
+                break;
+            }
+            // not verified: the iterate is intact but for the slots that held the classes; its residuals are
+            // recomputed (S.rd served as scratch) and the interior-point iteration goes on
+            ROWS_BEGIN(k, rw)
+                if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = R.prod(k, rw.e);
+            ROWS_END
+            tried = true;
+            mode = 0;
+            continue;
+        }
+        tried = false;
         STAMP(3);
         double g1 = 0;
         g1 = wPv<D>(p, S, lane, S.w1);
@@ -1612,6 +1779,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         }
         STAMP(6);
         if (!(tau > 0) || !(kap >= 0)) { status = HMPC_NUMERICAL; break; }
+        it++;
     }
 #ifdef HMPC_STAMPS
     if (trace && lane == 0)
@@ -1753,7 +1921,8 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         // the second direction is dead while a factorisation runs: its storage doubles as the
         // factorisation scratch (stage matrix, carried identity block, Pn [A B])
-        const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + nx * nz;
+        // (the register factorisation keeps the dense terminal block of the last stage behind the stage matrix)
+        const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + (D::kKC > 0 ? nz * nz : nx * nz);
         S.w2 = take(dir2 > fscr ? dir2 : fscr); S.lam2 = S.w2 + n; S.nuf2 = S.lam2 + (T + 1) * nx;
         S.Mm = S.w2; S.PA = S.Mm + nz * nz;
         S.q = take(nx); S.mv = take(nz); S.red = take(40);
@@ -1825,6 +1994,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
             S.fullfix = __ballot(all);
         }
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
+        bool polished = false;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
         // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
@@ -1834,7 +2004,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, tr ? tr + term_on * 64 * 8 : nullptr);
+            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, tr ? tr + term_on * 64 * 8 : nullptr);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -1851,7 +2021,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
         __syncthreads();
         write_record<D>(p, S, lane, status, tau, qp, out);
-        if (lane == 0 && out.iters) out.iters[qp] = it1 + it2;
+        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0);
     }
 }
 

@@ -30,7 +30,8 @@ class _Problem(ctypes.Structure):
 
 class _Options(ctypes.Structure):
     _fields_ = [('tol', ctypes.c_double), ('tol_inf', ctypes.c_double), ('max_iter', ctypes.c_int32),
-                ('lazy_terminal', ctypes.c_int32), ('refine', ctypes.c_int32), ('device', ctypes.c_int32)]
+                ('lazy_terminal', ctypes.c_int32), ('refine', ctypes.c_int32), ('device', ctypes.c_int32),
+                ('polish', ctypes.c_int32), ('reserved', ctypes.c_int32), ('polish_tol', ctypes.c_double)]
 
 
 class _Result(ctypes.Structure):
@@ -87,11 +88,12 @@ class HipBatchedQP(object):
     """Batched QP-relaxation solver on one MI355X.
 
     problem : dict as returned by ``HybridModelPredictiveController.problem_data()``
-    tol, tol_inf, max_iter, lazy_terminal, refine : see ``hmpc_options`` in include/hmpc.h
+    tol, tol_inf, max_iter, lazy_terminal, refine, polish, polish_tol : see ``hmpc_options`` in include/hmpc.h
     device : HIP device ordinal (-1: current device)
     """
 
-    def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, lazy_terminal=True, refine=True, device=-1):
+    def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, lazy_terminal=True, refine=True, device=-1,
+                 polish=True, polish_tol=1e-4):
         self.lib = load_library()
         keep = {}
         for k in ('A', 'B', 'F', 'G', 'F_Tm1', 'G_Tm1', 'Q', 'R', 'Q_T'):
@@ -110,7 +112,8 @@ class HipBatchedQP(object):
                      nq=keep['Q'].shape[0], nr=keep['R'].shape[0], nqT=keep['Q_T'].shape[0],
                      **{k: v.ctypes.data_as(_dp) for k, v in keep.items()})
         o = _Options(tol=tol, tol_inf=tol_inf, max_iter=int(max_iter), lazy_terminal=int(bool(lazy_terminal)),
-                     refine=int(bool(refine)), device=int(device))
+                     refine=int(bool(refine)), device=int(device), polish=int(bool(polish)), reserved=0,
+                     polish_tol=float(polish_tol))
         handle = ctypes.c_void_p()
         rc = self.lib.hmpc_create(ctypes.byref(p), ctypes.byref(o), ctypes.byref(handle))
         if rc != 0:
@@ -157,6 +160,8 @@ class HipBatchedQP(object):
         tic = time.perf_counter()
         self._check(self.lib.hmpc_solve_batch(self.handle, x0.ctypes.data, stride, fix.ctypes.data, B, ctypes.byref(res)))
         out['time'] = time.perf_counter() - tic
+        out['polished'] = (out['iters'] >> 16) & 1      # HMPC_ITERS_POLISHED
+        out['iters'] = out['iters'] & 0xFFFF
         return out
 
     def solve_batch_device(self, x0, fix, out, stream=None):
