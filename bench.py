@@ -39,25 +39,27 @@ def cpu_baseline(ctrl, x0, fix):
     # the box gives each GPU a share of the host cores (16 per GPU); never oversubscribe beyond it
     cores = min(len(os.sched_getaffinity(0)), 16)
     orc = OracleBatchedQP(ctrl.problem_data(), threads=cores)
-    orc.solve_batch(x0, fix[:min(64, len(fix))])
-    best = None
-    for _ in range(2):
-        t = time.perf_counter()
-        orc.solve_batch(x0, fix)
-        dt = time.perf_counter() - t
-        best = dt if best is None else min(best, dt)
+
+    def timed(solver, x, f, warm=3, reps=10):       # 3 warm-up batches, median of >= 10
+        for _ in range(warm):
+            solver.solve_batch(x, f)
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            solver.solve_batch(x, f)
+            ts.append(time.perf_counter() - t)
+        return float(np.median(ts))
+    best = timed(orc, x0, fix)
     one = OracleBatchedQP(ctrl.problem_data(), threads=1)
-    sub = fix[:min(512, len(fix))]
-    t = time.perf_counter()
-    one.solve_batch(x0, sub)
-    t1 = time.perf_counter() - t
+    sub = fix[:min(256, len(fix))]
+    t1 = timed(one, x0, sub)
     try:  # time the reference's own engine only if it exists on this host
         import gurobipy  # noqa: F401
         gurobi = 'importable (not timed: no Gurobi-backed QP path is part of this repository)'
     except Exception:
         gurobi = 'unavailable on this host (proprietary, not in the image): the CPU baseline is the oracle port'
     return {'value': len(fix) / best, 'unit': 'QP subproblems/s', 'cores': cores, 'kind': 'port', 'gurobi': gurobi,
-            'sample': '%d-node frontier of this run, OpenMP over nodes, best of 2' % len(fix),
+            'sample': '%d-node frontier of this run, OpenMP over nodes, 3 warm-ups, median of 10 batches (single thread: first %d nodes)' % (len(fix), len(sub)),
             'single_thread_value': len(sub) / t1}
 
 
@@ -95,6 +97,114 @@ def shift_bandwidth(ctrl, dev, leaves=65536, trees=64, reps=10):
     return {'leaves': B, 'trees': K, 'kernel_ms_avg': ms, 'algorithmic_bytes_per_leaf': bytes_per_leaf,
             'achieved_GBs': gbs, 'peak_GBs': HBM_PEAK_GBS, 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
             'kernel': 'hmpc_shift_kernel'}
+
+
+def _device_rate(qp, x0_h, fix_h, dev, reps=5, warm=2):
+    """QP/s of one frontier, inputs resident in HBM, HIP events on the launch stream; statuses and iteration counts."""
+    import torch
+    B = fix_h.shape[0]
+    fix = torch.from_numpy(np.ascontiguousarray(fix_h)).to(dev)
+    x0 = torch.from_numpy(np.ascontiguousarray(x0_h)).to(dev)
+    out = dict(obj=torch.empty(B, dtype=torch.float64, device=dev), dual_obj=torch.empty(B, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
+               primal=torch.empty(B, qp.n_primal, dtype=torch.float64, device=dev),
+               dual=torch.empty(B, qp.n_dual, dtype=torch.float64, device=dev))
+    for _ in range(warm):
+        qp.solve_batch_device(x0, fix, out)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        qp.solve_batch_device(x0, fix, out)
+        b.record()
+    torch.cuda.synchronize()
+    ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    status = out['status'].cpu().numpy()
+    raw = out['iters'].cpu().numpy()
+    grid, lds = qp.launch_info()
+    return {'nodes': B, 'kernel_ms_avg': ms, 'qp_per_s': B / (ms * 1e-3), 'optimal': int((status == 0).sum()),
+            'infeasible': int((status == 1).sum()), 'not_converged': int((status > 1).sum()),
+            'polished': int(((raw >> 16) & 1).sum()), 'ipm_iters_mean': float((raw & 0xFFFF).mean()), 'grid': grid,
+            'lds_bytes_per_wg': lds}, status
+
+
+def secondary_frontiers(ctrl, dev, x0_h):
+    """The other frontiers of SURVEY 8(d) C2 on the headline system (the headline line is the p = 0.5 stress variant,
+    97.7 % infeasible): p = 0.1, the replayed real tree, the 1024-node size of BASELINE configs[2], and -- from one
+    large random frontier -- optimal and infeasible nodes apart."""
+    from helpers import random_prefix_frontier
+    T, nub = ctrl.T, ctrl.mld.nub
+    out = {}
+    r, _ = _device_rate(ctrl.qp, x0_h, random_prefix_frontier(T, nub, 4096, p_one=0.1), dev)
+    out['random_prefix_p0.1_4096'] = r
+    r, _ = _device_rate(ctrl.qp, x0_h, random_prefix_frontier(T, nub, 1024, p_one=0.5), dev)
+    out['random_prefix_p0.5_1024_configs2_size'] = r
+    # replayed real frontier: every node a cold-started search solves from x0 plus its leaves, tiled
+    seen, inner = [], ctrl.solve_frontier
+
+    def recording(identifiers, x0):
+        seen.extend(ctrl._fix_vector(i) for i in identifiers)
+        return inner(identifiers, x0)
+    ctrl.solve_frontier = recording
+    try:
+        _, leaves, _, _ = ctrl.feedforward(x0_h, printing_period=None)
+    finally:
+        ctrl.solve_frontier = inner
+    nodes = np.array(seen + [ctrl._fix_vector(l.identifier) for l in leaves], dtype=np.int8)
+    for size in (1024, 4096):
+        r, _ = _device_rate(ctrl.qp, x0_h, np.tile(nodes, (size // len(nodes) + 1, 1))[:size], dev)
+        out['replayed_real_tree_%d' % size] = r
+    # optimal and infeasible nodes apart (the same count of each, drawn from p = 0.1 frontiers)
+    pool = random_prefix_frontier(T, nub, 32768, p_one=0.1, seed0=200000)
+    _, status = _device_rate(ctrl.qp, x0_h, pool, dev, reps=1, warm=0)
+    n = min(int((status == 0).sum()), 2048)
+    r, _ = _device_rate(ctrl.qp, x0_h, pool[status == 0][:n], dev)
+    out['optimal_nodes_only'] = r
+    r, _ = _device_rate(ctrl.qp, x0_h, pool[status == 1][:n], dev)
+    out['infeasible_nodes_only'] = r
+    return out
+
+
+def other_configs(dev):
+    """BASELINE configs[3] (N = 40) and configs[4] (random MLD nx=20, nu=6+8, N=30) with their own algorithmic bytes."""
+    from helpers import make_controller, random_prefix_frontier, random_mld, _NoBackend
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    out = {}
+    c40 = make_controller('cart_pole_with_walls', T=40, backend='hip')
+    for name, f in (('cart_pole_N40_random_prefix_p0.1_2048', random_prefix_frontier(40, 4, 2048, p_one=0.1)),
+                    ('cart_pole_N40_random_prefix_p0.5_2048', random_prefix_frontier(40, 4, 2048, p_one=0.5))):
+        r, _ = _device_rate(c40.qp, np.array([0., 0., 1., 0.]), f, dev)
+        r['algorithmic_bytes_per_qp'] = c40.layout.bytes_per_qp()
+        r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
+        r['kernel'] = 'hmpc_qp_kernel<4,7,4,...> (static row map, %d bytes of LDS per node)' % r['lds_bytes_per_wg']
+        out[name] = r
+    # configs[4]: frontier = prefixes of a dive to a feasible leaf, every other one with a flipped binary (random
+    # prefixes are all infeasible for this generator), tiled
+    mld, objective, x0 = random_mld()
+    T, nub, nx = 30, 8, 20
+    c4 = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    c4.qp = HipBatchedQP(c4.problem_data())
+    Cj = np.array([mld.F[52 + 4 * j] for j in range(nub)])
+    leaf = np.full((1, T * nub), -1, np.int8)
+    for t in range(T):
+        rr = c4.qp.solve_batch(x0, leaf)
+        leaf[0, t * nub:(t + 1) * nub] = (rr['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+    rng = np.random.default_rng(0)
+    f = np.full((256, T * nub), -1, np.int8)
+    for k in range(1, 256):
+        d = int(rng.integers(1, T * nub + 1))
+        f[k, :d] = leaf[0, :d]
+        if k % 2 == 0:
+            j = int(rng.integers(0, d))
+            f[k, j] = 1 - f[k, j]
+    f = np.tile(f, (4, 1))
+    r, _ = _device_rate(c4.qp, x0, f, dev, reps=3, warm=1)
+    r['algorithmic_bytes_per_qp'] = c4.layout.bytes_per_qp()
+    r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
+    r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: lists and Riccati factor in global memory)'
+    out['random_mld_nx20_nu14_N30_dive_frontier_1024'] = r
+    return out
 
 
 def mpc_steps_per_sec(ctrl, steps=10, sims=64):
@@ -150,6 +260,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frontier', type=int, default=4096, help='nodes per GPU per step')
     ap.add_argument('--p-one', type=float, default=0.5)
+    ap.add_argument('--frontier-total', type=int, default=0,
+                    help='strong scaling: this many nodes IN TOTAL, split over the ranks (BASELINE configs[2]: 1024 over 8 GPUs); '
+                         'overrides --frontier')
+    ap.add_argument('--no-secondary', action='store_true', help='skip the secondary frontiers / configs / closed-loop figures')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='N > 1 ranks all on cuda:0 with a gloo group: rehearses the multi-rank path on a one-GPU box '
@@ -182,6 +296,10 @@ def main():
     ctrl = make_controller('cart_pole_with_walls', backend='hip', device=local)
     T, nub = ctrl.T, ctrl.mld.nub
     B = args.frontier
+    if args.frontier_total > 0:
+        if args.frontier_total % world:
+            raise SystemExit('--frontier-total must be a multiple of the number of ranks')
+        B = args.frontier_total // world
     # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1
     fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
     x0_h = np.array([0., 0., 1., 0.])
@@ -248,17 +366,18 @@ def main():
                 traffic_src = 'profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
         except (OSError, KeyError, ValueError):
             pass
+        polished = int(((out['iters'].cpu().numpy() >> 16) & 1).sum())
         line = {
             'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier',
             'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak' if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
+            'scaling': ('strong' if args.frontier_total > 0 else 'weak') if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': 'cart_pole_with_walls N=20, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), '
                                    'p_one=%.2f' % args.p_one,
                        'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist(), 'parallelism': 'frontier sharded by node, '
                        'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
-                       'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps'},
+                       'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps, active-set polish'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': bytes_per_qp * B,
@@ -271,7 +390,7 @@ def main():
                       'frac': 1.2e5 * float(iters.mean()) * B / (kernel_ms * 1e-3) / 1e12 / 78.6,
                       'note': 'neither bandwidth nor flops bound: sequential stage recursions, one wave per SIMD (DESIGN.md 5)'},
             'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
-                      'not_converged': int((status > 1).sum()), 'ipm_iters_mean': float(iters.mean())},
+                      'not_converged': int((status > 1).sum()), 'polished': polished, 'ipm_iters_mean': float(iters.mean())},
         }
         if world == 1:
             try:  # second kernel of the path (HBM bound), a few milliseconds
@@ -280,10 +399,13 @@ def main():
                 line['warm_start_shift'] = {'error': str(e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
-            try:
-                line['mpc_steps_per_sec'] = mpc_steps_per_sec(ctrl)
-            except Exception as e:  # secondary figure, never hides the main line
-                line['mpc_steps_per_sec'] = {'error': str(e)}
+        if world == 1 and not args.no_secondary and not args.no_cpu_baseline:
+            for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, x0_h)), ('other_configs', lambda: other_configs(dev)),
+                            ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl))):
+                try:
+                    line[key] = fn()
+                except Exception as e:  # secondary figures never hide the main line
+                    line[key] = {'error': repr(e)}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

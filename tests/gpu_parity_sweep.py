@@ -9,8 +9,8 @@ T = 20
 hip = make_controller('cart_pole_with_walls', T=T, backend='hip')
 orc = make_controller('cart_pole_with_walls', T=T, backend='oracle', threads=16)
 rng = np.random.default_rng(123)
-tot = bad_status = 0
-worst = 0.
+tot = bad_status = unpolished = 0
+worst = worst_fc = 0.
 nbig = 0
 for rep in range(int(os.environ.get('DBG_REPS', 24))):
     B = int(rng.choice([64, 300, 700, 2048, 4096]))
@@ -27,6 +27,10 @@ for rep in range(int(os.environ.get('DBG_REPS', 24))):
         dev = np.max(np.abs(xa - xb), axis=1) / np.maximum(1e-2, np.max(np.abs(xb), axis=1))
         worst = max(worst, float(dev.max()))
         nbig += int((dev > 1e-5).sum())
+        fa, fb = a['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, 7)[:, :, 0], b['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, 7)[:, :, 0]
+        worst_fc = max(worst_fc, float((np.max(np.abs(fa - fb), axis=1) / np.maximum(1e-2, np.max(np.abs(fb), axis=1))).max()))
+        unpolished += int((a['polished'][fin] == 0).sum())
     print('rep %2d B %4d p %.2f: status mismatches %d, not converged hip %d oracle %d, feasible %d, worst dev so far %.1e, > 1e-5: %d'
           % (rep, B, p_one, ns, int((a['status'] > 1).sum()), int((b['status'] > 1).sum()), int(fin.sum()), worst, nbig), flush=True)
-print('TOTAL nodes %d, status mismatches %d, worst trajectory deviation %.2e, nodes above 1e-5: %d' % (tot, bad_status, worst, nbig))
+print('TOTAL nodes %d, status mismatches %d, worst state-trajectory deviation %.2e (penalised input %.2e), nodes above 1e-5: %d, optimal nodes left unpolished by the kernel: %d'
+      % (tot, bad_status, worst, worst_fc, nbig, unpolished))

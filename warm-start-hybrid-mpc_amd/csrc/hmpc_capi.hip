@@ -342,6 +342,12 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         }
         h->allocs.push_back(p.fac_ws);
     }
+    if (hipMalloc((void **)&p.work_counter, sizeof(int)) != hipSuccess) {
+        hmpc_destroy(h);
+        return fail(HMPC_EDEVICE, "cannot allocate the work counter");
+    }
+    h->allocs.push_back(p.work_counter);
+    (void)hipMemset(p.work_counter, 0, sizeof(int));
     if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 4 * p.Mpad * sizeof(double)) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
@@ -496,6 +502,8 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     const int grid = B < cf.max_grid ? B : cf.max_grid;
     h->last_grid = grid;
     h->lds = cf.lds;
+    // (every launch: also a launch with B <= grid reads the counter once per workgroup, and what it reads must be >= 0)
+    HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), (hipStream_t)stream));
     hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace);
     HIPCHK(hipGetLastError());

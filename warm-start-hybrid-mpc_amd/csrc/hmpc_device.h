@@ -34,6 +34,7 @@ struct DevProb {
     int ngram;                                 // entries of C' D C with a nonempty term list (numbered first)
     const double *F_raw, *G_raw, *h_raw, *hT_raw; // unscaled [F G | h] and h_Tm1 (warm-start shift, hmpc_shift.hip)
     const double *shift_Mmu, *shift_Mrho, *shift_V; // maps of the shift (hmpc_set_shift_maps), null until set
+    int *work_counter;                         // nodes handed out beyond the first gridDim.x (zeroed before each launch)
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients

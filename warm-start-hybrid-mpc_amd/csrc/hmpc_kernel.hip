@@ -1982,7 +1982,11 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     R.bind(rows_ws + (size_t)blockIdx.x * 4 * p.Mpad, p.Mpad);
     RM rm;
     rm.init(p, lane);
-    for (int qp = blockIdx.x; qp < B; qp += gridDim.x) {
+    // Nodes differ in work (7 to 25 interior-point iterations, a second solve when the terminal set binds): the
+    // first gridDim.x nodes go to the workgroups by index, every further node to the first workgroup that is free
+    // (one atomic per node on a counter the host zeroes before the launch).  A record does not depend on the
+    // workgroup that computes it.
+    for (int qp = blockIdx.x; qp < B;) {
         __syncthreads();
         for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
         for (int i = lane; i < nx; i += D::kNT) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
@@ -2022,6 +2026,9 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         __syncthreads();
         write_record<D>(p, S, lane, status, tau, qp, out);
         if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0);
+        if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+        __syncthreads();
+        qp = S.flag[1];
     }
 }
 

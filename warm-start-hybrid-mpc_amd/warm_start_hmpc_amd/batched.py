@@ -262,13 +262,15 @@ class BatchedMPC(object):
         return out
 
     # ------------------------------------------------------------------
-    def closed_loop(self, x0, n_steps, e_sd=0., seeds=(0,), x_max=None, frontier_width=8, cold_too=False, log=None):
+    def closed_loop(self, x0, n_steps, e_sd=0., seeds=(0,), x_max=None, frontier_width=8, cold_too=False, log=None, errors=None):
         """Closed-loop Monte-Carlo study in the shape of statistical_analysis.py:93-207.
 
         One simulation per seed, all advanced in lockstep.  The disturbance of simulation i at step t is
         ``e_sd * RandomState(i).randn(nx) * x_max`` -- the stream of ``np.random.seed(i)`` that the
         reference draws from (statistical_analysis.py:73,176).  A simulation whose MIQP becomes infeasible
-        stops (the reference discards it, :99-108).
+        stops (the reference discards it, :99-108).  ``errors`` (len(seeds), n_steps, nx), if given, replaces the
+        random stream: the disturbances applied in the reference's published runs
+        (``notebooks/cart_pole_with_walls/data/errors_sd_*.npy``) can be replayed step by step.
 
         Returns dict: nodes_ws, nodes_cs (per sim, per step), len_ws, costs, alive steps, wall time, steps/s.
         """
@@ -279,7 +281,7 @@ class BatchedMPC(object):
         ws = [None] * K
         active = list(range(K))
         stats = dict(nodes_ws=[[] for _ in range(K)], nodes_cs=[[] for _ in range(K)], len_ws=[[] for _ in range(K)],
-                     costs=[[] for _ in range(K)], errors=[[] for _ in range(K)], cost_mismatches=[])
+                     costs=[[] for _ in range(K)], errors=[[] for _ in range(K)], reopened=[[] for _ in range(K)], cost_mismatches=[])
         tic = perf_counter()
         steps_done = 0
         for t in range(n_steps):
@@ -299,7 +301,7 @@ class BatchedMPC(object):
                 stats['nodes_ws'][k].append(r['solves'])
                 if not np.isfinite(r['objective']):
                     continue                        # infeasible: the simulation ends here
-                e_t = e_sd * rngs[k].randn(self.nx) * x_max
+                e_t = e_sd * rngs[k].randn(self.nx) * x_max if errors is None else np.asarray(errors[k][t], dtype=np.float64)
                 shifted.append((j, k, e_t))
             if shifted:
                 new_ws = self.construct_warm_start_many(
@@ -310,6 +312,7 @@ class BatchedMPC(object):
                 r = warm[j]
                 ws[k] = w
                 stats['len_ws'][k].append(len(ws[k]))
+                stats['reopened'][k].append(int((~ws[k].has_dual).sum()))   # infeasibility proofs lost in the shift
                 stats['costs'][k].append(r['objective'])
                 stats['errors'][k].append(e_t)
                 if log is not None:
