@@ -249,6 +249,23 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
         dt, rounds, solves = best
         out[label] = {'value': steps / dt, 'launches_per_step_mean': float(np.mean(rounds)),
                       'warm_solves_per_step_mean': float(np.mean(solves)), 'sample': 'best of 3 runs of %d steps' % steps}
+    # (d) the C++ fleet driver (hmpc_fleet_*, csrc/hmpc_fleet.hip): trees behind the handle, multiplier rows resident in
+    # HBM, one call per step for all loops; same disturbances for every driver (sigma = 0.001, seed = loop index)
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    for K, spec in ((1, 4), (64, 2), (256, 0), (1024, 0)):
+        errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
+        fl = FleetMPC(ctrl, K)
+        fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], frontier_width=8, speculation=spec)   # warm-up (allocations)
+        cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], frontier_width=8, speculation=spec)
+        s0 = fl.stats()
+        st = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, frontier_width=8, speculation=spec)
+        s1 = fl.stats()
+        dt = st['wall'] - cold['wall']                                                            # subtract the cold-start step
+        out['fleet_%d_loops' % K] = {'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
+                                     'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'speculation_depth': spec,
+                                     'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
+                                     'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
+        del fl
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
 

@@ -159,6 +159,32 @@ int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t 
                             const double *d_dual, const double *d_dual_obj, int8_t *d_fix_out, double *d_lb_out,
                             double *d_dual_out, double *d_dual_obj_out, uint8_t *d_flags, void *stream);
 
+/* ---- Closed loops in lockstep ("fleet") ---------------------------------------------------------------
+ * K independent closed loops of the controller advanced together -- the shape of the reference's Monte-Carlo
+ * study (notebooks/cart_pole_with_walls/statistical_analysis.py:93-196: per step one warm-started branch and
+ * bound, branch_and_bound.py:408-499 + controller.py:395-429, then construct_warm_start, controller.py:431-564).
+ * The trees live behind the handle: topology and bounds on the host, every multiplier row in HBM (written by
+ * the QP kernel, referenced by index, shifted in place by the shift kernel); one call per MPC step, the rounds
+ * of all trees share kernel launches.  Needs hmpc_set_shift_maps.  Per loop and step:
+ *     hmpc_fleet_solve : MIQP from x0[k] by branch and bound started from the loop's current tree (its root for a
+ *                        cold loop), `width` candidates per tree and round (1 = the reference's node order);
+ *                        speculation = k: descendants through the next k binaries ride in the launch of a
+ *                        node and are consumed only if the search gets there (same result, fewer launches);
+ *                        cost[k] (+inf: infeasible, the loop stops), u0[k] (nu: applied input), x1[k] (nx: the
+ *                        model's next state A x0 + B u0), solves[k], leaves[k]
+ *     hmpc_fleet_shift : the tree becomes the warm start of the next step given the model error e0[k] of the step
+ *                        (next state = x1 + e0); cover[k] nodes, reopened[k] of them lost their infeasibility proof
+ * Any output pointer may be NULL.  hmpc_fleet_reset(f, k) makes loop k (-1: all) cold again. */
+typedef struct hmpc_fleet hmpc_fleet;
+int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out);
+int hmpc_fleet_destroy(hmpc_fleet *f);
+int hmpc_fleet_reset(hmpc_fleet *f, int32_t k);
+int hmpc_fleet_solve(hmpc_fleet *f, const double *x0 /* K x nx */, int32_t width, int32_t speculation, double tol, double *cost,
+                     double *u0, double *x1, int32_t *solves, int32_t *leaves);
+int hmpc_fleet_shift(hmpc_fleet *f, const double *e0 /* K x nx */, int32_t *cover, int32_t *reopened);
+/* kernel launches (rounds) and nodes sent to the QP kernel since creation */
+int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
+
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);
 

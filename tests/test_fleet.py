@@ -1,0 +1,77 @@
+"""The C++ fleet driver (hmpc_fleet_*, csrc/hmpc_fleet.hip: K closed loops in lockstep, trees behind the handle, multiplier
+rows resident in HBM) against the numpy lockstep driver (batched.BatchedMPC) and the reference's published runs."""
+import numpy as np
+import pytest
+
+from helpers import make_controller, load_fixture
+from warm_start_hmpc_amd.batched import BatchedMPC
+
+pytestmark = pytest.mark.gpu
+X0 = np.array([0., 0., 1., 0.])
+
+
+def test_fleet_walks_the_walk_of_the_numpy_driver():
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    ref = load_fixture('reference_closed_loop')
+    ctrl = make_controller('cart_pole_with_walls', backend='hip')
+    K, steps = 6, 12
+    errors = ref['errors_0003'][:K, :steps]
+    fl = FleetMPC(ctrl, K).closed_loop(X0, steps, errors, frontier_width=8)
+    py = BatchedMPC(ctrl).closed_loop(X0, steps, seeds=tuple(range(K)), frontier_width=8, errors=errors)
+    np.testing.assert_allclose(fl['costs'], np.array(py['costs']), rtol=1e-9, atol=1e-12)     # same optimum at every step
+    assert np.array_equal(fl['len_ws'], np.array(py['len_ws']))                                 # same covers
+    assert np.array_equal(fl['reopened'], np.array(py['reopened']))
+    # solve counts: the same search up to the order in which equal bounds are met (the two drivers batch differently,
+    # so a node may be solved by the 1-, 2- or 4-wave kernel: last-digit differences in the multipliers)
+    assert np.max(np.abs(fl['nodes_ws'] - np.array(py['nodes_ws']))) <= 6
+    assert abs(fl['nodes_ws'][:, 1:].mean() - np.array(py['nodes_ws'])[:, 1:].mean()) < 0.5
+
+
+def test_fleet_replays_the_published_runs():
+    # the reference's own disturbances (tests/golden/reference_closed_loop.npz), frontier_width 1 = its node order
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    ref = load_fixture('reference_closed_loop')
+    ctrl = make_controller('cart_pole_with_walls', backend='hip')
+    for tag in ('0001', '0003'):
+        st = FleetMPC(ctrl, 12).closed_loop(X0, 50, ref['errors_' + tag], frontier_width=1)
+        assert st['steps'] == 600
+        assert np.array_equal(st['len_ws'], ref['nodes_len_ws_' + tag])                        # published cover sizes, every step
+        ws, pws = st['nodes_ws'][:, 1:], ref['nodes_ws_' + tag][:, 1:]
+        calm = st['len_ws'][:, :-1] == 77
+        assert np.median(ws[calm] - st['reopened'][:, :-1][calm]) == 9                         # dive + lost proofs (test_reference_replay.py)
+        assert ws.mean() <= pws.mean() and ws.mean() >= 8.0
+        assert abs(st['nodes_ws'][:, 0].mean() - ref['nodes_cs_' + tag][:, 0].mean()) <= 3    # step 0 is a cold start
+
+
+def test_speculative_expansion_in_the_fleet_changes_launches_not_results():
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    ref = load_fixture('reference_closed_loop')
+    ctrl = make_controller('cart_pole_with_walls', backend='hip')
+    errors = ref['errors_0003'][:2, :8]
+    a, b = FleetMPC(ctrl, 2), FleetMPC(ctrl, 2)
+    plain = a.closed_loop(X0, 8, errors, frontier_width=1)
+    spec = b.closed_loop(X0, 8, errors, frontier_width=1, speculation=4, cold_speculation=4)
+    np.testing.assert_allclose(spec['costs'], plain['costs'], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(spec['len_ws'], plain['len_ws']) and np.array_equal(spec['reopened'], plain['reopened'])
+    assert np.max(np.abs(spec['nodes_ws'] - plain['nodes_ws'])) <= 4           # (kernel variant differs with the batch size)
+    assert b.stats()['rounds'] < a.stats()['rounds'] / 2 and b.stats()['launched'] > a.stats()['launched']
+
+
+def test_fleet_stops_a_loop_whose_miqp_is_infeasible_and_resets():
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    ctrl = make_controller('cart_pole_with_walls', backend='hip')
+    fl = FleetMPC(ctrl, 3)
+    x0s = np.array([X0, [0., 0., 5., 0.], X0 * 0.5])          # the second state is outside the feasible set
+    r = fl.solve(x0s)
+    assert np.isfinite(r['cost'][0]) and np.isinf(r['cost'][1]) and np.isfinite(r['cost'][2])
+    assert np.all(np.isnan(r['u0'][1]))
+    cover, _ = fl.shift(np.zeros((3, 4)))
+    assert cover[0] == 77 and cover[1] == 0
+    r2 = fl.solve(np.array([r['x1'][0], X0, r['x1'][2]]))
+    assert np.isinf(r2['cost'][1]) and r2['solves'][1] == 0       # ended loops stay ended ...
+    fl.reset(1)
+    r3 = fl.solve(np.array([r2['x1'][0], X0, r2['x1'][2]]))
+    assert np.isfinite(r3['cost'][1]) and r3['solves'][1] > 150   # ... until reset: a cold start
+    single = ctrl.feedforward(X0, printing_period=None)
+    assert abs(r3['cost'][1] - single[0].objective) < 1e-9
+    assert fl.stats()['rounds'] > 0

@@ -396,6 +396,8 @@ extern "C" int hmpc_set_shift_maps(hmpc_handle *h, const hmpc_shift_maps *m)
     return HMPC_OK;
 }
 
+static int hmpc_launch_shift(hmpc_handle *h, const ShiftArgs &a, void *stream);
+
 extern "C" int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t *d_owner, const double *d_x0,
                                        const double *d_u0, const double *d_e0, const int8_t *d_fix, const double *d_lb,
                                        const double *d_dual, const double *d_dual_obj, int8_t *d_fix_out, double *d_lb_out,
@@ -411,7 +413,14 @@ extern "C" int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, con
         return fail(HMPC_EINVAL, "null argument");
     if (d_dual == d_dual_out || d_fix == d_fix_out) return fail(HMPC_EINVAL, "the shift is not in place");
     HIPCHK(hipSetDevice(h->device));
-    ShiftArgs a{B, K, d_owner, d_x0, d_u0, d_e0, d_fix, d_lb, d_dual, d_dual_obj, d_fix_out, d_lb_out, d_dual_out, d_dual_obj_out, d_flags};
+    ShiftArgs a{B, K, d_owner, d_x0, d_u0, d_e0, d_fix, d_lb, d_dual, d_dual_obj, nullptr, d_fix_out, d_lb_out, d_dual_out, d_dual_obj_out, d_flags};
+    return hmpc_launch_shift(h, a, stream);
+}
+
+// (shared with the fleet driver, which passes a row indirection)
+static int hmpc_launch_shift(hmpc_handle *h, const ShiftArgs &a, void *stream)
+{
+    const int B = a.B;
     // persistent workgroups: enough to fill the device, each wave walks leaves with stride grid * SHIFT_WAVES
     const bool staged = hmpc_shift_lds_doubles(h->dp, true) * sizeof(double) <= 64 * 1024;
     const size_t lds = hmpc_shift_lds_doubles(h->dp, staged) * sizeof(double);
@@ -583,3 +592,5 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     }
     return HMPC_OK;
 }
+
+#include "hmpc_fleet.hip" // closed loops in lockstep (same translation unit: uses the launchers above)

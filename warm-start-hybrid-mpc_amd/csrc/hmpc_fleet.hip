@@ -1,0 +1,481 @@
+// hmpc_fleet.hip -- K closed loops advanced in lockstep behind the C ABI (include/hmpc.h, hmpc_fleet_*).
+//
+// What it replaces: the loop body of the reference's closed-loop study (notebooks/cart_pole_with_walls/
+// statistical_analysis.py:93-196; plot_trajectory.py:19-45) -- per MPC step one warm-started branch and bound
+// (warm_start_hmpc/branch_and_bound.py:408-499 with the brancher of controller.py:395-429) and one construction
+// of the next warm start (controller.py:431-564) -- for K independent loops at once.
+//
+// Why here and not in Python: at a few hundred trees the per-node bookkeeping of an interpreted driver costs more
+// than the kernels (round 1: 2 k steps/s against 500 k QP/s of kernel capacity).  The split is
+//   host (this file): tree topology and bounds -- identifiers, lower bounds, which dual row a node carries; candidate
+//     selection, prune / incumbent / branch; a few kilobytes per tree;
+//   device: every multiplier.  A solved node's dual row is written by the QP kernel straight into a row pool and never
+//     leaves HBM; children reference their parent's row by index; the node shift (hmpc_shift.hip) reads the leaves'
+//     rows through that index and writes the next step's pool.  Per round the host uploads the candidates'
+//     identifiers and initial states (112 B per node) and downloads objective, status and the multipliers of the
+//     binaries' bounds (1.3 KB per node) through pinned staging, on one stream.
+// Semantics per tree are those of warm_start_hmpc_amd/batched.py (feedforward_many / construct_warm_start_many),
+// against which tests/test_fleet.py checks it step by step.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+struct FleetResult { // a solved node waiting to be consumed by the search (speculative expansion)
+    double obj, nu_lb, nu_ub; // objective; multipliers of the two bounds of the next binary in time
+    int32_t row;              // its row in the pools
+};
+
+struct FleetTree {
+    std::vector<int8_t> fix;   // n x nfix, -1 free / 0 / 1 (chronological prefixes)
+    std::vector<double> lb;    // lower bound, +inf: proved infeasible
+    std::vector<int32_t> row;  // dual row of the current pool the node carries (own if solved, else parent's), -1: none
+    std::vector<uint8_t> alive;
+    std::vector<int16_t> depth; // fixed binaries
+    int n = 0;
+    double ub = std::numeric_limits<double>::infinity();
+    int inc = -1;               // incumbent node
+    std::vector<double> primal; // its primal row
+    int solves = 0;
+    bool running = true;        // false once the MIQP of a step was infeasible (the loop has ended)
+    std::vector<double> x0;     // state of the last solve
+    std::unordered_map<std::string, FleetResult> cache; // key: the fixed prefix of the identifier
+};
+
+struct hmpc_fleet {
+    hmpc_handle *h = nullptr;
+    int K = 0;
+    std::vector<FleetTree> trees;
+    hipStream_t stream = nullptr;
+    double *pool[2] = {nullptr, nullptr}, *dobj[2] = {nullptr, nullptr};
+    double *ppool = nullptr; // primal rows of the current step's solved nodes (same row index as pool[cur])
+    size_t cap_rows = 0, used = 0;
+    int cur = 0;
+    // per-round device buffers and their pinned host mirrors
+    size_t cap_b = 0;
+    int8_t *d_fix = nullptr, *h_fix = nullptr, *d_fix_out = nullptr;
+    double *d_x0 = nullptr, *h_x0 = nullptr, *d_obj = nullptr, *h_obj = nullptr, *d_primal = nullptr, *h_nu = nullptr;
+    int32_t *d_status = nullptr, *h_status = nullptr, *d_iters = nullptr;
+    int32_t *d_owner = nullptr, *h_owner = nullptr, *d_src = nullptr, *h_src = nullptr;
+    double *d_lb = nullptr, *h_lb = nullptr, *d_lb_out = nullptr;
+    uint8_t *d_flags = nullptr, *h_flags = nullptr;
+    double *d_kx0 = nullptr, *d_ku0 = nullptr, *d_ke0 = nullptr, *h_k = nullptr; // K x nx, K x nu, K x nx (pinned: 3 blocks)
+    double *h_prow = nullptr;                                                  // pinned: one primal row
+    long long rounds = 0, launched = 0;
+};
+
+namespace {
+
+template <class T> int dev_alloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+template <class T> int pin_alloc(T **p, size_t n) { return hipHostMalloc((void **)p, (n ? n : 1) * sizeof(T), hipHostMallocDefault) == hipSuccess ? 0 : -1; }
+
+void fleet_free_round(hmpc_fleet *f)
+{
+    for (void *d : {(void *)f->d_fix, (void *)f->d_fix_out, (void *)f->d_x0, (void *)f->d_obj, (void *)f->d_primal, (void *)f->d_status, (void *)f->d_iters,
+                    (void *)f->d_owner, (void *)f->d_src, (void *)f->d_lb, (void *)f->d_lb_out, (void *)f->d_flags})
+        if (d) (void)hipFree(d);
+    for (void *d : {(void *)f->h_fix, (void *)f->h_x0, (void *)f->h_obj, (void *)f->h_nu, (void *)f->h_status, (void *)f->h_owner, (void *)f->h_src,
+                    (void *)f->h_lb, (void *)f->h_flags})
+        if (d) (void)hipHostFree(d);
+    f->d_fix = f->h_fix = f->d_fix_out = nullptr;
+    f->d_x0 = f->h_x0 = f->d_obj = f->h_obj = f->d_primal = f->h_nu = nullptr;
+    f->d_status = f->h_status = f->d_iters = nullptr;
+    f->d_owner = f->h_owner = f->d_src = f->h_src = nullptr;
+    f->d_lb = f->h_lb = f->d_lb_out = nullptr;
+    f->d_flags = f->h_flags = nullptr;
+    f->cap_b = 0;
+}
+
+int fleet_ensure_round(hmpc_fleet *f, size_t B)
+{
+    if (B <= f->cap_b) return HMPC_OK;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    fleet_free_round(f);
+    const DevProb &p = f->h->dp;
+    const size_t cap = std::max<size_t>(2 * B, 1024), nfix = (size_t)p.T * p.nub;
+    int bad = 0;
+    bad |= dev_alloc(&f->d_fix, cap * nfix) | pin_alloc(&f->h_fix, cap * nfix) | dev_alloc(&f->d_fix_out, cap * nfix);
+    bad |= dev_alloc(&f->d_x0, cap * p.nx) | pin_alloc(&f->h_x0, cap * p.nx);
+    bad |= dev_alloc(&f->d_obj, cap) | pin_alloc(&f->h_obj, cap);
+    bad |= pin_alloc(&f->h_nu, cap * 2 * nfix);
+    bad |= dev_alloc(&f->d_status, cap) | pin_alloc(&f->h_status, cap) | dev_alloc(&f->d_iters, cap);
+    bad |= dev_alloc(&f->d_owner, cap) | pin_alloc(&f->h_owner, cap) | dev_alloc(&f->d_src, cap) | pin_alloc(&f->h_src, cap);
+    bad |= dev_alloc(&f->d_lb, cap) | pin_alloc(&f->h_lb, cap) | dev_alloc(&f->d_lb_out, cap);
+    bad |= dev_alloc(&f->d_flags, cap) | pin_alloc(&f->h_flags, cap);
+    if (bad) return fail(HMPC_EDEVICE, "fleet: cannot allocate the round buffers");
+    f->cap_b = cap;
+    return HMPC_OK;
+}
+
+// Room for `rows` rows in both pools; the rows in use of the current pool are kept.
+int fleet_ensure_rows(hmpc_fleet *f, size_t rows)
+{
+    if (rows <= f->cap_rows) return HMPC_OK;
+    HIPCHK(hipStreamSynchronize(f->stream));
+    const DevProb &p = f->h->dp;
+    const size_t cap = std::max<size_t>(rows + rows / 2, 4096);
+    for (int s = 0; s < 2; s++) {
+        double *np_ = nullptr, *nd = nullptr;
+        if (dev_alloc(&np_, cap * p.n_dual) || dev_alloc(&nd, cap)) return fail(HMPC_EDEVICE, "fleet: cannot grow the row pools");
+        if (s == f->cur && f->used) {
+            HIPCHK(hipMemcpy(np_, f->pool[s], f->used * p.n_dual * sizeof(double), hipMemcpyDeviceToDevice));
+            HIPCHK(hipMemcpy(nd, f->dobj[s], f->used * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+        if (f->pool[s]) (void)hipFree(f->pool[s]);
+        if (f->dobj[s]) (void)hipFree(f->dobj[s]);
+        f->pool[s] = np_;
+        f->dobj[s] = nd;
+    }
+    {
+        double *pp = nullptr;
+        if (dev_alloc(&pp, cap * p.n_primal)) return fail(HMPC_EDEVICE, "fleet: cannot grow the row pools");
+        if (f->ppool && f->used) HIPCHK(hipMemcpy(pp, f->ppool, f->used * p.n_primal * sizeof(double), hipMemcpyDeviceToDevice));
+        if (f->ppool) (void)hipFree(f->ppool);
+        f->ppool = pp;
+    }
+    f->cap_rows = cap;
+    return HMPC_OK;
+}
+
+void tree_reset_cold(FleetTree &t, int nfix)
+{
+    t.fix.assign(nfix, (int8_t)-1);
+    t.lb.assign(1, -std::numeric_limits<double>::infinity());
+    t.row.assign(1, -1);
+    t.alive.assign(1, 1);
+    t.depth.assign(1, 0);
+    t.n = 1;
+    t.running = true;
+}
+
+} // namespace
+
+extern "C" int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out)
+{
+    g_err.clear();
+    if (!h || !out || K < 1) return fail(HMPC_EINVAL, "fleet: null handle or K < 1");
+    if (!h->dp.shift_Mmu) return fail(HMPC_EINVAL, "fleet: hmpc_set_shift_maps has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    hmpc_fleet *f = new hmpc_fleet();
+    f->h = h;
+    f->K = K;
+    const DevProb &p = h->dp;
+    f->trees.resize(K);
+    for (auto &t : f->trees) {
+        tree_reset_cold(t, p.T * p.nub);
+        t.x0.assign(p.nx, 0.0);
+    }
+    if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return fail(HMPC_EDEVICE, "fleet: cannot create a stream"); }
+    int bad = dev_alloc(&f->d_kx0, (size_t)K * p.nx) | dev_alloc(&f->d_ku0, (size_t)K * p.nu) | dev_alloc(&f->d_ke0, (size_t)K * p.nx);
+    bad |= pin_alloc(&f->h_k, (size_t)K * (2 * p.nx + p.nu)) | pin_alloc(&f->h_prow, (size_t)p.n_primal);
+    if (bad) { hmpc_fleet_destroy(f); return fail(HMPC_EDEVICE, "fleet: cannot allocate"); }
+    *out = f;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_fleet_destroy(hmpc_fleet *f)
+{
+    if (!f) return HMPC_OK;
+    (void)hipSetDevice(f->h->device);
+    if (f->stream) (void)hipStreamSynchronize(f->stream);
+    fleet_free_round(f);
+    for (int s = 0; s < 2; s++) {
+        if (f->pool[s]) (void)hipFree(f->pool[s]);
+        if (f->dobj[s]) (void)hipFree(f->dobj[s]);
+    }
+    for (void *d : {(void *)f->d_kx0, (void *)f->d_ku0, (void *)f->d_ke0, (void *)f->ppool})
+        if (d) (void)hipFree(d);
+    if (f->h_k) (void)hipHostFree(f->h_k);
+    if (f->h_prow) (void)hipHostFree(f->h_prow);
+    if (f->stream) (void)hipStreamDestroy(f->stream);
+    delete f;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_fleet_reset(hmpc_fleet *f, int32_t k)
+{
+    if (!f || k < -1 || k >= f->K) return fail(HMPC_EINVAL, "fleet: bad loop index");
+    const int nfix = f->h->dp.T * f->h->dp.nub;
+    for (int i = (k < 0 ? 0 : k); i < (k < 0 ? f->K : k + 1); i++) tree_reset_cold(f->trees[i], nfix);
+    return HMPC_OK;
+}
+
+// One MPC step of every running loop: branch and bound from the loop's current tree (the root for a cold loop).
+// speculation = k > 0: with every candidate that has to be solved, its descendants through the next k binaries (2 + 4 +
+// ... + 2^k nodes) ride in the same launch; their results wait in a per-tree cache and are consumed -- unchanged -- if and
+// when the search selects them, so incumbent, leaves and solve counts are those of the search without speculation and only
+// the number of launches drops (a warm-started step: from five to one or two).  Worth it for few loops (latency), a waste
+// for many (throughput).
+extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, int32_t speculation, double tol, double *cost,
+                                double *u0, double *x1, int32_t *solves, int32_t *n_leaves)
+{
+    g_err.clear();
+    if (!f || !x0) return fail(HMPC_EINVAL, "fleet: null argument");
+    if (width < 1) width = 1;
+    if (speculation < 0) speculation = 0;
+    hmpc_handle *h = f->h;
+    HIPCHK(hipSetDevice(h->device));
+    const DevProb &p = h->dp;
+    const int K = f->K, nfix = p.T * p.nub, nx = p.nx, nu = p.nu;
+    const int o_lb = (p.T + 1) * nx + (p.T - 1) * p.nc + p.ncL; // nu_lb then nu_ub, contiguous in the dual row
+    const double inf = std::numeric_limits<double>::infinity();
+    for (int k = 0; k < K; k++) {
+        FleetTree &t = f->trees[k];
+        t.ub = inf; t.inc = -1; t.solves = 0;
+        t.cache.clear();
+        std::memcpy(t.x0.data(), x0 + (size_t)k * nx, nx * sizeof(double));
+    }
+    std::vector<std::vector<int>> picks(K);
+    std::vector<int> order;
+    struct Launch { int k, depth; };
+    std::vector<Launch> launch;
+    std::vector<int8_t> level, next; // identifiers of one level of a speculative expansion
+    auto key_of = [&](const int8_t *fx, int depth) { return std::string((const char *)fx, (size_t)depth); };
+    for (;;) {
+        // candidates of every tree: alive, bound below the incumbent; the `width` smallest bounds, first wins ties
+        size_t npick = 0;
+        for (int k = 0; k < K; k++) {
+            FleetTree &t = f->trees[k];
+            picks[k].clear();
+            if (!t.running) continue;
+            order.clear();
+            for (int i = 0; i < t.n; i++)
+                if (t.alive[i] && t.lb[i] < t.ub - tol) order.push_back(i);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.lb[a] < t.lb[b]; });
+            if ((int)order.size() > width) order.resize(width);
+            picks[k] = order;
+            npick += order.size();
+        }
+        if (npick == 0) break;
+        // what has to be launched: picked nodes without a cached result, and their speculative descendants
+        launch.clear();
+        size_t B = 0;
+        int rc;
+        for (int pass = 0; pass < 2; pass++) { // pass 0 counts, pass 1 fills the staging buffers
+            if (pass == 1) {
+                if (B == 0) break;
+                if ((rc = fleet_ensure_round(f, B))) return rc;
+                if ((rc = fleet_ensure_rows(f, f->used + B))) return rc;
+            }
+            size_t b = 0;
+            for (int k = 0; k < K; k++) {
+                FleetTree &t = f->trees[k];
+                for (int i : picks[k]) {
+                    const int8_t *fx = t.fix.data() + (size_t)i * nfix;
+                    if (t.cache.count(key_of(fx, t.depth[i]))) continue;
+                    level.assign(fx, fx + nfix);
+                    int depth = t.depth[i];
+                    for (int s = 0; s <= speculation; s++) {
+                        const size_t cnt = level.size() / nfix;
+                        next.clear();
+                        for (size_t q = 0; q < cnt; q++) {
+                            const int8_t *row = level.data() + q * nfix;
+                            if (s == 0 || !t.cache.count(key_of(row, depth))) {
+                                if (pass == 1) {
+                                    std::memcpy(f->h_fix + b * nfix, row, nfix);
+                                    std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
+                                    launch.push_back({k, depth});
+                                }
+                                b++;
+                            }
+                            if (s < speculation && depth < nfix)
+                                for (int v = 0; v < 2; v++) {
+                                    next.insert(next.end(), row, row + nfix);
+                                    next[next.size() - nfix + depth] = (int8_t)v;
+                                }
+                        }
+                        if (next.empty()) break;
+                        level.swap(next);
+                        depth++;
+                    }
+                }
+            }
+            B = b;
+        }
+        if (B > 0) {
+            HIPCHK(hipMemcpyAsync(f->d_fix, f->h_fix, B * nfix, hipMemcpyHostToDevice, f->stream));
+            HIPCHK(hipMemcpyAsync(f->d_x0, f->h_x0, B * nx * sizeof(double), hipMemcpyHostToDevice, f->stream));
+            double *rows = f->pool[f->cur] + f->used * p.n_dual;
+            hmpc_result r{f->d_obj, f->dobj[f->cur] + f->used, f->d_status, f->d_iters, f->ppool + f->used * p.n_primal, rows};
+            if ((rc = hmpc_solve_batch_device(h, f->d_x0, nx, f->d_fix, (int32_t)B, &r, f->stream))) return rc;
+            HIPCHK(hipMemcpyAsync(f->h_obj, f->d_obj, B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipMemcpyAsync(f->h_status, f->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipMemcpy2DAsync(f->h_nu, 2 * nfix * sizeof(double), rows + o_lb, p.n_dual * sizeof(double), 2 * nfix * sizeof(double), B,
+                                    hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipStreamSynchronize(f->stream));
+            f->rounds++;
+            f->launched += (long long)B;
+            for (size_t q = 0; q < B; q++) {
+                if (f->h_status[q] > 1) return fail(HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
+                const int d = launch[q].depth;
+                const double *nu_ = f->h_nu + q * 2 * nfix;
+                FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q)};
+                f->trees[launch[q].k].cache.emplace(key_of(f->h_fix + q * nfix, d), e);
+            }
+            f->used += B;
+        }
+        // prune / incumbent / branch, node by node in selection order (branch_and_bound.py:476-489)
+        for (int k = 0; k < K; k++) {
+            FleetTree &t = f->trees[k];
+            for (int i : picks[k]) {
+                auto it = t.cache.find(key_of(t.fix.data() + (size_t)i * nfix, t.depth[i]));
+                if (it == t.cache.end()) return fail(HMPC_EDEVICE, "fleet: a selected node has no result");
+                const FleetResult e = it->second;
+                t.cache.erase(it);
+                const double obj = e.obj;
+                t.solves++;
+                t.lb[i] = obj;
+                t.row[i] = e.row;
+                const double cutoff = t.ub - tol;
+                if (obj >= cutoff) continue;
+                const int d = t.depth[i];
+                if (d == nfix) { // every binary fixed: new incumbent
+                    t.ub = obj;
+                    t.inc = i;
+                    HIPCHK(hipMemcpy(f->h_prow, f->ppool + (size_t)e.row * p.n_primal, p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
+                    t.primal.assign(f->h_prow, f->h_prow + p.n_primal);
+                } else { // branch on the next binary in time; child bound = parent bound + multiplier of the tightened bound
+                    for (int v = 0; v < 2; v++) {
+                        const size_t c = t.n;
+                        t.fix.resize((c + 1) * nfix);
+                        std::memcpy(t.fix.data() + c * nfix, t.fix.data() + (size_t)i * nfix, nfix);
+                        t.fix[c * nfix + d] = (int8_t)v;
+                        t.lb.push_back(obj + (v == 1 ? e.nu_lb : e.nu_ub));
+                        t.row.push_back(e.row);
+                        t.alive.push_back(1);
+                        t.depth.push_back((int16_t)(d + 1));
+                        t.n++;
+                    }
+                    t.alive[i] = 0;
+                }
+            }
+        }
+    }
+    for (int k = 0; k < K; k++) {
+        FleetTree &t = f->trees[k];
+        t.cache.clear();
+        if (cost) cost[k] = t.running ? t.ub : inf;
+        if (solves) solves[k] = t.solves;
+        if (n_leaves) {
+            int c = 0;
+            for (int i = 0; i < t.n; i++) c += t.alive[i];
+            n_leaves[k] = t.running ? c : 0;
+        }
+        const bool ok = t.running && t.inc >= 0;
+        for (int j = 0; j < nu && u0; j++) u0[(size_t)k * nu + j] = ok ? t.primal[(size_t)(p.T + 1) * nx + j] : NAN;
+        for (int j = 0; j < nx && x1; j++) x1[(size_t)k * nx + j] = ok ? t.primal[nx + j] : NAN;
+        if (t.running && t.inc < 0) t.running = false; // infeasible MIQP: the loop ends here (statistical_analysis.py:99-108)
+    }
+    return HMPC_OK;
+}
+
+// The next step's warm start of every running loop (controller.py:431-564): retain rule on the host (it only needs the
+// identifiers and the applied binaries), everything that touches multipliers in one launch of the shift kernel.
+extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover, int32_t *reopened)
+{
+    g_err.clear();
+    if (!f || !e0) return fail(HMPC_EINVAL, "fleet: null argument");
+    hmpc_handle *h = f->h;
+    HIPCHK(hipSetDevice(h->device));
+    const DevProb &p = h->dp;
+    const int K = f->K, nfix = p.T * p.nub, nx = p.nx, nu = p.nu, nub = p.nub, nuc = p.nuc;
+    // kept leaves of all trees
+    std::vector<std::vector<int>> keep(K);
+    size_t B = 0;
+    for (int k = 0; k < K; k++) {
+        FleetTree &t = f->trees[k];
+        if (cover) cover[k] = 0;
+        if (reopened) reopened[k] = 0;
+        if (!t.running || t.inc < 0) continue;
+        const double *u = t.primal.data() + (size_t)(p.T + 1) * nx;
+        for (int i = 0; i < t.n; i++) {
+            if (!t.alive[i]) continue;
+            bool agree = true;
+            for (int q = 0; q < nub && agree; q++) {
+                const int fq = t.fix[(size_t)i * nfix + q];
+                agree = fq < 0 || fq == (int)std::rint(u[nuc + q]);
+            }
+            if (agree) keep[k].push_back(i);
+        }
+        B += keep[k].size();
+    }
+    if (B == 0) return HMPC_OK;
+    int rc = fleet_ensure_round(f, B);
+    if (rc) return rc;
+    if ((rc = fleet_ensure_rows(f, std::max(f->used, B)))) return rc;
+    double *hx = f->h_k, *hu = hx + (size_t)K * nx, *he = hu + (size_t)K * nu;
+    size_t b = 0;
+    for (int k = 0; k < K; k++) {
+        FleetTree &t = f->trees[k];
+        std::memcpy(hx + (size_t)k * nx, t.x0.data(), nx * sizeof(double));
+        std::memcpy(he + (size_t)k * nx, e0 + (size_t)k * nx, nx * sizeof(double));
+        for (int j = 0; j < nu; j++) hu[(size_t)k * nu + j] = keep[k].empty() ? 0.0 : t.primal[(size_t)(p.T + 1) * nx + j];
+        for (int i : keep[k]) {
+            if (t.row[i] < 0) return fail(HMPC_EINVAL, "fleet: a leaf carries no multipliers (unsolved root?)");
+            std::memcpy(f->h_fix + b * nfix, t.fix.data() + (size_t)i * nfix, nfix);
+            f->h_owner[b] = k;
+            f->h_src[b] = t.row[i];
+            f->h_lb[b] = t.lb[i];
+            b++;
+        }
+    }
+    HIPCHK(hipMemcpyAsync(f->d_kx0, hx, (size_t)K * nx * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_ku0, hu, (size_t)K * nu * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_ke0, he, (size_t)K * nx * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_fix, f->h_fix, B * nfix, hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_owner, f->h_owner, B * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_src, f->h_src, B * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+    HIPCHK(hipMemcpyAsync(f->d_lb, f->h_lb, B * sizeof(double), hipMemcpyHostToDevice, f->stream));
+    const int nxt = f->cur ^ 1;
+    ShiftArgs a{(int)B, K, f->d_owner, f->d_kx0, f->d_ku0, f->d_ke0, f->d_fix, f->d_lb, f->pool[f->cur], f->dobj[f->cur], f->d_src,
+                f->d_fix_out, f->d_lb_out, f->pool[nxt], f->dobj[nxt], f->d_flags};
+    if ((rc = hmpc_launch_shift(h, a, f->stream))) return rc;
+    HIPCHK(hipMemcpyAsync(f->h_lb, f->d_lb_out, B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipMemcpyAsync(f->h_flags, f->d_flags, B, hipMemcpyDeviceToHost, f->stream));
+    HIPCHK(hipStreamSynchronize(f->stream));
+    // the shifted leaves are the next tree: identifiers move one stage towards the present
+    b = 0;
+    std::vector<int8_t> nfixv;
+    for (int k = 0; k < K; k++) {
+        FleetTree &t = f->trees[k];
+        if (keep[k].empty()) continue;
+        const size_t n = keep[k].size();
+        nfixv.assign(n * nfix, (int8_t)-1);
+        std::vector<double> lb(n);
+        std::vector<int32_t> row(n);
+        std::vector<int16_t> depth(n);
+        int reop = 0;
+        for (size_t j = 0; j < n; j++, b++) {
+            const int i = keep[k][j];
+            if (!(f->h_flags[b] & 1)) return fail(HMPC_EDEVICE, "fleet: host and device disagree on the retain rule");
+            std::memcpy(nfixv.data() + j * nfix, t.fix.data() + (size_t)i * nfix + nub, nfix - nub);
+            lb[j] = f->h_lb[b];
+            const bool re = (f->h_flags[b] & 2) != 0;
+            reop += re;
+            row[j] = (int32_t)b; // (a reopened leaf carries its row too: it is re-solved before anything reads it)
+            depth[j] = (int16_t)std::max(0, (int)t.depth[i] - nub);
+        }
+        t.fix = nfixv;
+        t.lb = lb;
+        t.row = row;
+        t.depth = depth;
+        t.alive.assign(n, 1);
+        t.n = (int)n;
+        if (cover) cover[k] = (int32_t)n;
+        if (reopened) reopened[k] = reop;
+    }
+    f->cur = nxt;
+    f->used = B;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched)
+{
+    if (!f) return fail(HMPC_EINVAL, "fleet: null");
+    if (rounds) *rounds = f->rounds;
+    if (launched) *launched = f->launched;
+    return HMPC_OK;
+}

@@ -22,6 +22,7 @@ struct ShiftArgs {
     const double *x0, *u0, *e0;
     const int8_t *fix;
     const double *lb, *dual, *dobj;
+    const int32_t *src; // row of dual / dobj that leaf b carries (children share their parent's row); null: row b
     int8_t *fix_out;
     double *lb_out, *dual_out, *dobj_out;
     uint8_t *flags;
@@ -80,13 +81,14 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) hmpc_shift_kernel(const DevP
         const int own = a.owner[b];
         const double *x0g = a.x0 + (size_t)own * nx, *u0g = a.u0 + (size_t)own * nu, *e0 = a.e0 + (size_t)own * nx;
         const int8_t *fix = a.fix + (size_t)b * T * nub;
-        const double *d = a.dual + (size_t)b * p.n_dual;
+        const size_t srow = a.src ? (size_t)a.src[b] : (size_t)b;
+        const double *d = a.dual + srow * p.n_dual;
         double *o = a.dual_out + (size_t)b * p.n_dual;
         // retain rule (controller.py:566-613): the binaries the leaf fixes at time 0 are the applied ones
         int agree = 1;
         if (lane < nub) {
             const int f = fix[lane];
-            agree = f < 0 || f == (int)u0g[nuc + lane];
+            agree = f < 0 || f == (int)rint(u0g[nuc + lane]);
         }
         agree = __all(agree);
         if (!agree) { // dropped: nothing else is defined for this leaf
@@ -106,7 +108,7 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) hmpc_shift_kernel(const DevP
         const double nulb0 = lane < nub ? d[o_lb + lane] : 0.0, nuub0 = lane < nub ? d[o_ub + lane] : 0.0;
         const double lam1 = lane < nx ? d[nx + lane] : 0.0, e0v = lane < nx ? e0[lane] : 0.0;
         const int fix0 = lane < nub ? fix[lane] : -1;
-        const double dobj_in = a.dobj[b], lb_in = a.lb[b];
+        const double dobj_in = a.dobj[srow], lb_in = a.lb[b];
         // identifier: drop time 0, the stage that enters is free
         int8_t *fo = a.fix_out + (size_t)b * T * nub;
         for (int i = lane; i < T * nub; i += 64) fo[i] = i < (T - 1) * nub ? fix[i + nub] : (int8_t)-1;

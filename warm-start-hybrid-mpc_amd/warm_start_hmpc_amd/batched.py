@@ -197,7 +197,7 @@ class BatchedMPC(object):
         mld = c.mld
         u0 = np.concatenate((uc0, ub0))
         first = leaves.fix[:, :nub]
-        keep = np.all((first < 0) | (first == ub0.astype(np.int8)), axis=1)        # _retain_leaf
+        keep = np.all((first < 0) | (first == np.rint(ub0).astype(np.int8)), axis=1)   # _retain_leaf
         fix, lb, dual, dobj = leaves.fix[keep], leaves.lb[keep].copy(), leaves.dual[keep], leaves.dobj[keep]
         has_dual = leaves.has_dual[keep].copy()
         n = len(lb)

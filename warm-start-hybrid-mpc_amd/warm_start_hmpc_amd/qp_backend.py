@@ -75,13 +75,27 @@ def load_library():
         lib.hmpc_shift_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 13
         lib.hmpc_shift_batch_device.restype = ctypes.c_int
         lib.hmpc_shift_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32] + [ctypes.c_void_p] * 14
+        lib.hmpc_fleet_create.restype = ctypes.c_int
+        lib.hmpc_fleet_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p)]
+        lib.hmpc_fleet_destroy.restype = ctypes.c_int
+        lib.hmpc_fleet_destroy.argtypes = [ctypes.c_void_p]
+        lib.hmpc_fleet_reset.restype = ctypes.c_int
+        lib.hmpc_fleet_reset.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        lib.hmpc_fleet_solve.restype = ctypes.c_int
+        lib.hmpc_fleet_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double] + [ctypes.c_void_p] * 5
+        lib.hmpc_fleet_shift.restype = ctypes.c_int
+        lib.hmpc_fleet_shift.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.hmpc_fleet_stats.restype = ctypes.c_int
+        lib.hmpc_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         _lib = lib
     return _lib
 
 
 EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
-                    'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device')
+                    'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
+                    'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
+                    'hmpc_fleet_stats')
 
 
 class HipBatchedQP(object):
