@@ -7,7 +7,7 @@ set -e -o pipefail
 TAG=${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=$GRAFT_REPO_ROOT/gpurun_out
-B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+B="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary"
 rm -rf $O/${TAG}_*
 timeout -k 10 300 python3 bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- $B > $O/${TAG}_stats.log 2>&1

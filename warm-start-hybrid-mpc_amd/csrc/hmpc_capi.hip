@@ -181,6 +181,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     p.max_iter = opt && opt->max_iter > 0 ? opt->max_iter : 100;
     p.lazy = opt ? opt->lazy_terminal : 1;
     p.refine = opt ? opt->refine : 1;
+    p.dbg = getenv("HMPC_DBG") ? atoi(getenv("HMPC_DBG")) : 0;
     p.polish = opt ? opt->polish : 1;
     p.ptol = opt && opt->polish_tol > 0 ? opt->polish_tol : 1e-4;
 
@@ -309,6 +310,12 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
     const size_t lds_cu = 160 * 1024;
     if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
+    // generic kernel on the matrix cores (nz >= 16): the dense stage rows go to LDS if they fit beside everything else
+    p.dense_c_lds = 0;
+    if (p.nz >= 16) {
+        const bool big = hmpc_lds_bytes(p, 0, 0) > lds_cu || getenv("HMPC_FORCE_BIG");
+        if (hmpc_lds_bytes(p, 0, big ? 1 : 0) + (size_t)p.mreg * p.nz * sizeof(double) <= lds_cu) p.dense_c_lds = 1;
+    }
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
     for (int c = 0; c < 3; c++) {
@@ -505,7 +512,9 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
-    const int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
+    int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
+    // the streaming form holds one node per CU whatever the number of waves: always spread it over all four SIMDs
+    if (h->cfg[2].k.big && !getenv("HMPC_WAVES")) nw = 4;
     const hmpc_cfg &cf = h->cfg[nw == 1 ? 0 : nw == 2 ? 1 : 2];
     const hmpc_kernel_choice &k = cf.k;
     const int grid = B < cf.max_grid ? B : cf.max_grid;

@@ -37,6 +37,7 @@ struct DevProb {
     int *work_counter;                         // nodes handed out beyond the first gridDim.x (zeroed before each launch)
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
+    int dense_c_lds;                           // generic kernel: the dense stage rows are staged in LDS (they fit beside the rest)
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
@@ -44,6 +45,7 @@ struct DevProb {
     double cs;                                 // cost scale
     double tol, tol_inf;
     int max_iter, lazy, refine;
+    int dbg;                                   // diagnostic build only (HMPC_DBG): phases to skip when timing
     int polish;                                // active-set polish of optimal iterates (hmpc_options.polish)
     double ptol;                               //   tried once the scaled residuals and gap are below ptol
 };
@@ -85,6 +87,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
         d += 2 * (size_t)p.nnz0;                                          // rval0 cval0
         i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0;                   // rptr0 rcol0 cptr0 crow0
     }
+    if (kc == 0 && p.dense_c_lds) d += (size_t)p.mreg * nz;                 // dense stage rows for the matrix-core contractions
     return d * sizeof(double) + i * sizeof(int) + b;
 }
 

@@ -42,7 +42,8 @@
 #define HMPC_POLISH_RHO 1e5
 #define HMPC_POLISH_DELTA 1e-10
 #define HMPC_POLISH_ITERS 5
-#define HMPC_POLISH_ROUNDS 10
+#define HMPC_POLISH_ROUNDS 6
+#define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #ifndef HMPC_KERNEL_ATTR
 #define HMPC_KERNEL_ATTR
 #endif
@@ -51,6 +52,7 @@
 // Diagnostic build only (-DHMPC_STAMPS): cycle stamps per phase of the interior-point loop,
 // accumulated for node 0 into the trace buffer.  No stamp executes in the shipped kernel.
 #ifdef HMPC_STAMPS
+#define DBG_SKIP(bit) (p.dbg & (1 << (bit)))
 #define STAMP(k) do { long long now_ = clock64(); tacc[k] += now_ - tlast; tlast = clock64(); } while (0)
 #define FSTAMP(k) do { long long now_ = clock64(); facc[k] += now_ - flast; flast = clock64(); } while (0)
 #define FSTAMP_DECL long long flast = clock64()
@@ -58,12 +60,22 @@ static __device__ long long facc_dump[16];
 #define FSTAMP_ARGS , long long *facc
 #define FSTAMP_PASS , facc
 #else
+#define DBG_SKIP(bit) false
 #define STAMP(k) do { } while (0)
 #define FSTAMP(k) do { } while (0)
 #define FSTAMP_DECL do { } while (0)
 #define FSTAMP_ARGS
 #define FSTAMP_PASS
 #endif
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter (its
+// release covers global memory): in a loop whose threads exchange data through LDS alone but also issue global
+// stores nobody reads before the kernel's next full barrier (the multipliers of the streaming factorisation),
+// that drain puts one HBM / L2 write latency on every step.
+DEV void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 DEV double wave_sum(double v)
 {
@@ -183,6 +195,7 @@ struct Lds {
     ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
     ListsG G0;         // the same lists left in global memory, and the Riccati factor in a global slab:
     double *LmG, *PrG; //   the streaming variant for problems whose factor does not fit in LDS (Dims::kBig)
+    const ldsd *Cd;    // generic kernel: the stage rows as a dense mreg x nz matrix for the matrix-core contractions (null: read p.Creg)
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
@@ -575,8 +588,9 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 #define LM_X(nx, nu, x, j) ((x) * (nu) + (j))                       /* state row x, pivot j     */
 #define LM_U(nx, nu, i, j) ((nx) * (nu) + (i) * ((i) - 1) / 2 + (j)) /* input row i, pivot j < i */
 
-template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
+template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
+    FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     for (int e = lane; e < nx * nx; e += D::kNT) {
@@ -591,6 +605,14 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
         const auto Lm = fac_lm<D>(S) + t * lms;
         int nfixed = 0;
         for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
+        if (DBG_SKIP(0)) {
+            for (int e = lane; e < nz * nz; e += D::kNT) S.Mm[e] = (e / nz == e % nz) ? 2.0 : 0.0;
+            __syncthreads();
+        } else if (nz >= 16 && p.mreg < 65536) {
+            // dense contractions on the matrix cores; P_{t+1} is still where the previous stage's elimination
+            // left it (the leading nx x nx block of S.Mm), the terminal Hessian for the last stage
+            stage_matrix_mfma<D>(p, S, lane, t, t == T - 1 ? S.PT : S.Mm, t == T - 1 ? nx : nz);
+        } else {
         // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
         for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
@@ -605,6 +627,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             S.PA[e] = a;
         }
         __syncthreads();
+        FSTAMP(0);
         for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             double a = S.Mm[i * nz + j];
@@ -613,7 +636,10 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             S.Mm[j * nz + i] = a;
         }
         __syncthreads();
-        for (int e = lane; e < lms; e += D::kNT) Lm[e] = 0.0;
+        }
+        FSTAMP(1);
+        if (!DBG_SKIP(1))
+            for (int e = lane; e < lms; e += D::kNT) Lm[e] = 0.0;
         if (nfixed) {
             for (int i = lane; i < nz; i += D::kNT) {
                 double a = 0;
@@ -633,7 +659,8 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
             for (int i = lane; i < nz; i += D::kNT) S.g[t * nz + i] = 0.0;
             __syncthreads();
         }
-        for (int j = 0; j < nu; j++) {
+        FSTAMP(2);
+        for (int j = 0; j < (DBG_SKIP(2) ? 0 : nu); j++) {
             if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot: the solves skip it as well
                 if (lane == 0) S.dinv[t * nu + j] = 1.0;
                 continue;
@@ -654,18 +681,111 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane)
                 const int k = bcol < nx ? bcol : pj + 1 + (bcol - nx);
                 const double mij = S.Mm[i * nz + pj] * rinv;
                 S.Mm[i * nz + k] -= mij * S.Mm[pj * nz + k];
-                if (bcol == 0) Lm[a < nx ? LM_X(nx, nu, a, j) : LM_U(nx, nu, i - nx, j)] = mij;
+                if (bcol == 0 && !DBG_SKIP(3)) Lm[a < nx ? LM_X(nx, nu, a, j) : LM_U(nx, nu, i - nx, j)] = mij;
             }
             if (lane == 0) S.dinv[t * nu + j] = rinv;
-            __syncthreads();
+            if constexpr (D::kNW > 1) lds_barrier(); // the pivot steps exchange S.Mm only; the multipliers go to memory in the background
         }
+        __syncthreads();
+        FSTAMP(3);
         for (int e = lane; e < nx * nx; e += D::kNT) {
             const int i = e / nx, j = e - i * nx;
             if (i >= j) fac_pr<D>(S)[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
         }
         __syncthreads();
+        FSTAMP(4);
     }
     return bad ? -1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The stage matrix of the run-time-sized kernel on the matrix cores (problems with nz >= 16, e.g. BASELINE
+// configs[4]: nx = 20, nu = 14, 100 rows per stage).  All three contractions of
+//   M = P + C' D C + [A B]' P_{t+1} [A B]
+// are dense 16 x 16 x 4 tiles of v_mfma_f64_16x16x4_f64 (lane l feeds A[row l & 15][k = l >> 4] and
+// B[k = l >> 4][col l & 15]; it receives rows (l >> 4) + 4 r, r < 4, of column l & 15): C is read as the dense
+// mreg x nz matrix the host keeps for the static row map (L2 resident, the same for every node), D from the
+// row vector in LDS, P_{t+1} from the LDS block the previous stage's elimination left it in.  The waves of the
+// node share the tiles; the lower triangle is computed and mirrored.  The list walk it replaces spent its time
+// on dependent global loads (index, then value) -- 70 k cycles per stage against ~3 k here.
+// ---------------------------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+template <class FA, class FB> DEV mfma_d4 mfma_tile(int wl, int K, FA a, FB b, mfma_d4 acc)
+{
+    const int r = wl & 15, kq = wl >> 4;
+    int k0 = 0;
+    for (; k0 + 8 <= K; k0 += 8) { // two steps per round: the loads of the second are in flight under the first MFMA
+        const double a0 = a(r, k0 + kq), b0 = b(k0 + kq, r), a1 = a(r, k0 + 4 + kq), b1 = b(k0 + 4 + kq, r);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) {
+        const int k = k0 + kq;
+        const double av = k < K ? a(r, k) : 0.0, bv = k < K ? b(k, r) : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// Pn: cost-to-go Hessian of stage t + 1 as a dense block with row stride pns (LDS).  Result in S.Mm (dense nz x nz).
+template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, int lane, int t, const ldsd *Pn, int pns)
+{
+    const int nx = D::nx(p), nz = D::nz(p);
+    const int wl = lane & 63, wave = lane >> 6;
+    const int tn = (nz + 15) >> 4, tx = (nx + 15) >> 4;
+    // (1) PA = P_{t+1} [A B]  (nx x nz)
+    for (int q = wave; q < tx * tn; q += D::kNW) {
+        const int ti = q / tn, tj = q - ti * tn;
+        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        acc = mfma_tile(wl, nx,
+                        [&](int r, int k) { const int i = ti * 16 + r; return i < nx ? Pn[i * pns + k] : 0.0; },
+                        [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.AB[k * nz + j] : 0.0; }, acc);
+        const int j = tj * 16 + (wl & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = ti * 16 + (wl >> 4) + 4 * r;
+            if (i < nx && j < nz) S.PA[i * nz + j] = acc[r];
+        }
+    }
+    __syncthreads();
+    // (2) M = P + C' D C + [A B]' PA, lower-triangle tiles
+    const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
+    const bool term = S.term_on && t == p.T - 1;
+    for (int q = wave; q < tn * (tn + 1) / 2; q += D::kNW) {
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+        const int tj = q - ti * (ti + 1) / 2;
+        mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+        if (S.Cd)
+            acc = mfma_tile(wl, p.mreg,
+                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? S.Cd[k * nz + i] * Dt[k] : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.Cd[k * nz + j] : 0.0; }, acc);
+        else
+            acc = mfma_tile(wl, p.mreg,
+                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? p.Creg[(size_t)k * nz + i] * Dt[k] : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? p.Creg[(size_t)k * nz + j] : 0.0; }, acc);
+        if (term) {
+            const ldsd *De = S.e + p.Toff;
+            acc = mfma_tile(wl, p.nT,
+                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? p.Ct[(size_t)k * nz + i] * De[k] : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? p.Ct[(size_t)k * nz + j] : 0.0; }, acc);
+        }
+        acc = mfma_tile(wl, nx,
+                        [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? S.AB[k * nz + i] : 0.0; },
+                        [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.PA[k * nz + j] : 0.0; }, acc);
+        const int j = tj * 16 + (wl & 15);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int i = ti * 16 + (wl >> 4) + 4 * r;
+            if (i < nz && j < nz) {
+                const double v = acc[r] + S.P[i * nz + j];
+                S.Mm[i * nz + j] = v;
+                if (ti != tj) S.Mm[j * nz + i] = v;
+            }
+        }
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1289,6 +1409,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
     polished_out = false;
     bool tried = false; // the polish has been tried (and failed) on the current iterate
+    int attempts = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
 #ifdef HMPC_STAMPS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
@@ -1406,7 +1527,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             // default): nothing more can be gained from the interior-point iteration on an interior-free node
             const bool exhausted = status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
                                    rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol;
-            polish = p.polish && !tried &&
+            polish = p.polish && !tried && attempts < HMPC_POLISH_ATTEMPTS &&
                      (acceptable || exhausted || (status != HMPC_OPTIMAL && rcinf / tau <= p.ptol * (1 + winf / tau + x0inf) &&
                                                   rdinf / tau <= p.ptol * (1 + zinf / tau) && gap <= gptol));
             if (polish) {
@@ -1462,14 +1583,24 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 const double zr = R.z(k, rw.e); // zero on rows that take no part in this solve
                 double d = 0.0;
                 if (zr != 0.0) {
+                    // active: z > s, or -- Tapia indicators over the last step (dz and ds are still in place) -- the
+                    // slack shrinks faster than the multiplier: s+/s < z+/z; this reads weakly active rows right far
+                    // more often than z > s alone (2.2 instead of 3.3 active sets per polish)
+                    const double sr = R.s(k, rw.e);
+                    bool active = zr > sr;
+                    if (last_alpha > 0) {
+                        const double sp = sr - last_alpha * R.prod(k, rw.e), zp = zr - last_alpha * R.dz(k, rw.e);
+                        if (sp > 0 && zp > 0 && zr * sp > sr * zp) active = true;
+                    }
                     R.prod(k, rw.e) = zr; // kept for the way back
-                    if (zr > R.s(k, rw.e)) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
+                    if (active) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
                     else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
                     R.D(k, rw.e) = d;
                 }
                 S.e[rw.e] = d;
             ROWS_END
             mode = 1; round = 0; al = 0;
+            attempts++;
         } else {
             ROWS_BEGIN(k, rw)
                 const double zr = R.z(k, rw.e); // zero on inactive rows
@@ -1486,7 +1617,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (mode != 2) {
             int frc;
             if constexpr (D::kNX > 0) frc = factor_reg<D>(p, S, lane FSTAMP_PASS);
-            else frc = factor<D>(p, S, lane);
+            else frc = factor<D>(p, S, lane FSTAMP_PASS);
             STAMP(2);
             if (frc != 0) {
                 if (mode == 0) {
@@ -1782,10 +1913,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         it++;
     }
 #ifdef HMPC_STAMPS
-    if (trace && lane == 0)
-        for (int k = 0; k < 8; k++) trace[2 * 64 * 8 + (term_on ? 8 : 0) + k] = (double)tacc[k];
-    if (trace && lane == 0 && term_on == 0)
-        for (int k = 0; k < 16; k++) trace[2 * 64 * 8 + 16 + k] = (double)facc[k];
+    // (`trace` points at this solve's iteration rows: the stamp block follows the rows of both solves)
+    double *tb = trace ? trace - (term_on ? 64 * 8 : 0) + 2 * 64 * 8 : nullptr;
+    if (tb && lane == 0)
+        for (int k = 0; k < 8; k++) tb[(term_on ? 8 : 0) + k] = (double)tacc[k];
+    if (tb && lane == 0 && (term_on == 0 || p.nT == 0))
+        for (int k = 0; k < 16; k++) tb[16 + k] = (double)facc[k];
 #endif
     iters = it;
     tau_out = tau;
@@ -1934,6 +2067,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         constexpr bool NL = KC > 0 || D::kBig; // no row / column lists in LDS
         ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
         ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
+        ldsd *cd0 = take(p.dense_c_lds ? p.mreg * nz : 0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
         S.flag = takei(2);
@@ -1974,6 +2108,9 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
         S.G0 = ListsG{g0.rptr, g0.rcol, g0.cptr, g0.crow, g0.gptr, g0.grow, g0.rval, g0.cval, g0.gval, g0.h};
         S.ccv = cval0;
+        S.Cd = p.dense_c_lds ? cd0 : nullptr;
+        if (p.dense_c_lds)
+            for (int i = lane; i < p.mreg * nz; i += D::kNT) cd0[i] = p.Creg[i];
         S.cci = cci0;
         S.term_on = 0;
         S.fullfix = 0;
