@@ -88,6 +88,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
         i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0;                   // rptr0 rcol0 cptr0 crow0
     }
     if (kc == 0 && p.dense_c_lds) d += (size_t)p.mreg * nz;                 // dense stage rows for the matrix-core contractions
+    if (big) d += lms;                                                     // one stage's multipliers staged for the sweeps
     return d * sizeof(double) + i * sizeof(int) + b;
 }
 

@@ -195,6 +195,7 @@ struct Lds {
     ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
     ListsG G0;         // the same lists left in global memory, and the Riccati factor in a global slab:
     double *LmG, *PrG; //   the streaming variant for problems whose factor does not fit in LDS (Dims::kBig)
+    ldsd *Ls;          //   ... and one stage's multipliers staged in LDS for the sweeps of a solve
     const ldsd *Cd;    // generic kernel: the stage rows as a dense mreg x nz matrix for the matrix-core contractions (null: read p.Creg)
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
@@ -345,6 +346,22 @@ template <class L> DEV double gram(const L &st, int e, const ldsd *D)
 // C_t row / column products.  `base` is a row-indexed LDS vector (z, e, ...); `v` a stage vector.
 template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, const ldsd *v)
 {
+    if constexpr (D::kBig) {
+        // streaming form with the dense stage rows in LDS: a dense product there beats a list walk in global memory
+        // (two dependent loads per term at L2 latency)
+        if (S.Cd && lr < p.mreg) {
+            const int nz = D::nz(p);
+            const ldsd *c = S.Cd + lr * nz;
+            double a0 = 0, a1 = 0;
+            int j = 0;
+            for (; j + 2 <= nz; j += 2) {
+                a0 += c[j] * v[j];
+                a1 += c[j + 1] * v[j + 1];
+            }
+            if (j < nz) a0 += c[j] * v[j];
+            return a0 + a1;
+        }
+    }
     if (lr < p.mreg) return row_dot(stage_lists<D>(S), lr, v);
     const int nz = D::nz(p);
     const double *c = p.Ct + (size_t)(lr - p.mreg) * nz; // dense terminal row
@@ -382,6 +399,17 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
                 else a0 += cc[q] * ee[q];
             }
         }
+        a = a0 + a1;
+    } else if (D::kBig && S.Cd) {
+        const int nz = D::nz(p);
+        const ldsd *eb = base + t * p.mreg, *c = S.Cd + j;
+        double a0 = 0, a1 = 0;
+        int r = 0;
+        for (; r + 2 <= p.mreg; r += 2) {
+            a0 += c[r * nz] * eb[r];
+            a1 += c[(r + 1) * nz] * eb[r + 1];
+        }
+        if (r < p.mreg) a0 += c[r * nz] * eb[r];
         a = a0 + a1;
     } else {
         a = col_dot(stage_lists<D>(S), j, base + t * p.mreg);
@@ -638,8 +666,13 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
         __syncthreads();
         }
         FSTAMP(1);
+        // the stage's multipliers are collected in LDS (the streaming form flushes the block to its slab once per
+        // stage, coalesced, instead of one scattered global store per pivot and row)
+        ldsd *Lw;
+        if constexpr (D::kBig) Lw = S.Ls;
+        else Lw = S.Lm + t * lms;
         if (!DBG_SKIP(1))
-            for (int e = lane; e < lms; e += D::kNT) Lm[e] = 0.0;
+            for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
         if (nfixed) {
             for (int i = lane; i < nz; i += D::kNT) {
                 double a = 0;
@@ -675,19 +708,22 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
             // are not part of the trailing block.  The thread of the first trailing column keeps the
             // row's multiplier.
             const int nrem = nx + (nu - 1 - j);
+            const float inv_nrem = 1.0f / (float)nrem; // e / nrem through a float multiply: exact for e < 2^16
             for (int e = lane; e < nrem * nrem; e += D::kNT) {
-                const int a = e / nrem, bcol = e - a * nrem;
+                const int a = (int)(((float)e + 0.5f) * inv_nrem), bcol = e - a * nrem;
                 const int i = a < nx ? a : pj + 1 + (a - nx);
                 const int k = bcol < nx ? bcol : pj + 1 + (bcol - nx);
                 const double mij = S.Mm[i * nz + pj] * rinv;
                 S.Mm[i * nz + k] -= mij * S.Mm[pj * nz + k];
-                if (bcol == 0 && !DBG_SKIP(3)) Lm[a < nx ? LM_X(nx, nu, a, j) : LM_U(nx, nu, i - nx, j)] = mij;
+                if (bcol == 0 && !DBG_SKIP(3)) Lw[a < nx ? LM_X(nx, nu, a, j) : LM_U(nx, nu, i - nx, j)] = mij;
             }
             if (lane == 0) S.dinv[t * nu + j] = rinv;
-            if constexpr (D::kNW > 1) lds_barrier(); // the pivot steps exchange S.Mm only; the multipliers go to memory in the background
+            lds_barrier(); // the pivot steps exchange LDS data only
         }
         __syncthreads();
         FSTAMP(3);
+        if constexpr (D::kBig)
+            for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e];
         for (int e = lane; e < nx * nx; e += D::kNT) {
             const int i = e / nx, j = e - i * nx;
             if (i >= j) fac_pr<D>(S)[t * nxs + sym(i, j)] = S.Mm[i * nz + j];
@@ -1013,6 +1049,141 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
 // Generic form: every phase is spread over the threads, a barrier after each; the substitutions take
 // one barrier per pivot.
 // ---------------------------------------------------------------------------------------------
+// The two sweeps of a solve for the run-time-sized kernel when a stage vector fits one wave (nz <= 64): wave 0 runs the
+// recursion with lane j holding component j and v_readlane broadcasts -- no workgroup barrier per pivot (the barrier
+// form below pays one per pivot and, in the streaming form, a global-memory latency on top).  In the streaming form
+// the stage's multipliers are staged in LDS: the other waves fetch the next stage's block into registers while wave 0
+// works on the current one.  Skipped pivots (fixed binaries) have zero multipliers: their steps are no-ops.
+// On entry: S.g = stage gradients, S.pv[T] set.  On exit: dw (x and u), S.pv (p_t) as the barrier form leaves them.
+template <class D>
+DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, const ldsd *csrc, double cs, bool useb, ldsd *dw)
+{
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
+    const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
+    const bool w0 = lane < WAVE;
+    // S.pv[t] <- P_{t+1} c_t: the part of q_t = p_{t+1} + P_{t+1} c_t that does not depend on the recursion
+    for (int o = lane; o < T * nx; o += D::kNT) {
+        const int t = o / nx, i = o - t * nx;
+        double a = 0.0;
+        if (csrc) {
+            const auto Pn = fac_pr<D>(S) + (t + 1) * nxs;
+            for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * (cs * csrc[t * nx + l]);
+        }
+        S.pv[o] = a;
+    }
+    // staging of one stage's multipliers (streaming form): every thread but wave 0's carries part of the next block
+    constexpr int STG = 8; // doubles per fetching thread: covers lms <= 8 * (kNT - 64) (checked by the caller)
+    double stage_reg[STG];
+    const int fetchers = D::kNT > WAVE ? D::kNT - WAVE : D::kNT, fid = D::kNT > WAVE ? lane - WAVE : lane;
+    auto fetch = [&](int t) {
+        if constexpr (D::kBig) {
+            if (fid >= 0) {
+                const double *src = S.LmG + (size_t)t * lms;
+#pragma unroll
+                for (int q = 0; q < STG; q++) {
+                    const int e = fid + q * fetchers;
+                    stage_reg[q] = e < lms ? src[e] : 0.0;
+                }
+            }
+        }
+    };
+    auto commit = [&]() {
+        if constexpr (D::kBig) {
+            if (fid >= 0) {
+#pragma unroll
+                for (int q = 0; q < STG; q++) {
+                    const int e = fid + q * fetchers;
+                    if (e < lms) S.Ls[e] = stage_reg[q];
+                }
+            }
+        }
+    };
+    auto block = [&](int t) -> const ldsd * {
+        if constexpr (D::kBig) return S.Ls;
+        else return S.Lm + t * lms;
+    };
+    double pvr = 0.0; // lane i < nx of wave 0: p_{t+1}[i]
+    if (w0 && lane < nx) pvr = S.pv[T * nx + lane];
+    fetch(T - 1);
+    __syncthreads();
+    commit();
+    __syncthreads();
+    // ---- backward sweep
+    for (int t = T - 1; t >= 0; t--) {
+        if (D::kNT > WAVE ? !w0 : false) {
+            if (t > 0) fetch(t - 1);
+        } else if (w0) {
+            const ldsd *Lm = block(t);
+            const ldsi *fx = S.fix + t * nub;
+            const int j = lane;
+            const double qv = lane < nx ? pvr + S.pv[t * nx + lane] : 0.0;
+            const int jc = j < nz ? j : 0;
+            double v = j < nz ? S.g[t * nz + jc] : 0.0;
+            for (int l = 0; l < nx; l++) v += (j < nz ? S.AB[l * nz + jc] : 0.0) * bcast(qv, l);
+            if (j >= nx + nuc && j < nz) {
+                const int f = fx[j - nx - nuc];
+                if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
+            }
+            // forward substitution: the factorisation's row operations applied to the vector
+            const int rowoff = j < nx ? LM_X(nx, nu, j, 0) : j < nz ? LM_U(nx, nu, j - nx, 0) : 0;
+            const int rowlen = j < nx ? nu : j < nz ? j - nx : 0;
+            for (int jj = 0; jj < nu; jj++) {
+                const double yj = bcast(v, nx + jj);
+                if (jj < rowlen) v -= Lm[rowoff + jj] * yj;
+            }
+            if (j >= nx && j < nz) dw[t * nz + j] = v; // y = L_u^{-1} m_u, parked in the input slots
+            pvr = v;
+            if (j < nx) S.pv[t * nx + j] = v;
+        }
+        if constexpr (D::kBig) {
+            if (D::kNT == WAVE && t > 0) fetch(t - 1); // one wave only: it fetches for itself
+            __syncthreads();
+            if (t > 0) commit();
+            __syncthreads();
+        }
+    }
+    if constexpr (!D::kBig) __syncthreads();
+    // ---- forward sweep
+    fetch(0);
+    __syncthreads();
+    commit();
+    __syncthreads();
+    double xr = (w0 && lane < nx && usex0) ? S.x0[lane] : 0.0;
+    for (int t = 0; t < T; t++) {
+        if (D::kNT > WAVE ? !w0 : false) {
+            if (t + 1 < T) fetch(t + 1);
+        } else if (w0) {
+            const ldsd *Lm = block(t);
+            const int j = lane;
+            // c = L_x' x + dinv .* y ; x_next = c_dyn + A x (+ B u below)
+            double cur = j < nu ? S.dinv[t * nu + j] * dw[t * nz + nx + j] : 0.0;
+            double xn = (csrc && j < nx) ? cs * csrc[t * nx + j] : 0.0;
+            for (int l = 0; l < nx; l++) {
+                const double xl = bcast(xr, l);
+                if (j < nu) cur += Lm[LM_X(nx, nu, l, j)] * xl;
+                if (j < nx) xn += S.AB[j * nz + l] * xl;
+            }
+            // back substitution with L_u' ; u_jj = -(value of lane jj once its turn has come)
+            for (int jj = nu - 1; jj >= 0; jj--) {
+                const double uj = bcast(cur, jj);
+                if (j < jj) cur -= Lm[LM_U(nx, nu, jj, j)] * uj;
+                if (j < nx) xn -= S.AB[j * nz + nx + jj] * uj;
+            }
+            if (j < nx) dw[t * nz + j] = xr;
+            if (j < nu) dw[t * nz + nx + j] = -cur;
+            xr = xn;
+        }
+        if constexpr (D::kBig) {
+            if (D::kNT == WAVE && t + 1 < T) fetch(t + 1);
+            __syncthreads();
+            if (t + 1 < T) commit();
+            __syncthreads();
+        }
+    }
+    if (w0 && lane < nx) dw[T * nz + lane] = xr;
+    __syncthreads();
+}
+
 template <class D, int RS, class RM>
 DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
                    const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf)
@@ -1026,8 +1197,10 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     }
     for (int j = lane; j < nx; j += D::kNT) S.pv[T * nx + j] = -(gsrc ? gs * gsrc[T * nz + j] : 0.0);
     __syncthreads();
-    // backward sweep
-    for (int t = T - 1; t >= 0; t--) {
+    const bool wave_sweeps = nz <= WAVE && (!D::kBig || lms <= 8 * (D::kNT > WAVE ? D::kNT - WAVE : D::kNT));
+    if (wave_sweeps) kkt_sweeps_wave<D>(p, S, lane, usex0, csrc, cs, useb, dw);
+    // backward sweep (barrier form: stage vectors wider than a wave)
+    for (int t = wave_sweeps ? -1 : T - 1; t >= 0; t--) {
         const auto Lm = fac_lm<D>(S) + t * lms;
         const ldsi *fx = S.fix + t * nub;
         const ldsd *qv = S.pv + (t + 1) * nx;
@@ -1068,9 +1241,11 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         __syncthreads();
     }
     // forward sweep
-    for (int i = lane; i < nx; i += D::kNT) dw[i] = usex0 ? S.x0[i] : 0.0;
-    __syncthreads();
-    for (int t = 0; t < T; t++) {
+    if (!wave_sweeps) {
+        for (int i = lane; i < nx; i += D::kNT) dw[i] = usex0 ? S.x0[i] : 0.0;
+        __syncthreads();
+    }
+    for (int t = wave_sweeps ? T : 0; t < T; t++) {
         const auto Lm = fac_lm<D>(S) + t * lms;
         const ldsi *fx = S.fix + t * nub;
         const ldsd *x = dw + t * nz;
@@ -2068,6 +2243,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
         ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
         ldsd *cd0 = take(p.dense_c_lds ? p.mreg * nz : 0);
+        S.Ls = take(D::kBig ? LM_STAGE(nx, nu) : 0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
         S.flag = takei(2);
