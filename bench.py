@@ -281,6 +281,9 @@ def main():
                     help='strong scaling: this many nodes IN TOTAL, split over the ranks (BASELINE configs[2]: 1024 over 8 GPUs); '
                          'overrides --frontier')
     ap.add_argument('--no-secondary', action='store_true', help='skip the secondary frontiers / configs / closed-loop figures')
+    ap.add_argument('--workload', default='cart_pole_n20', choices=('cart_pole_n20', 'cart_pole_n40', 'random_mld'),
+                    help='cart_pole_n20: the headline (BASELINE configs[1]/[2]); the others (configs[3], configs[4]) are for profiling '
+                         'their kernels with the same harness -- their numbers are secondary keys of the default run')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='N > 1 ranks all on cuda:0 with a gloo group: rehearses the multi-rank path on a one-GPU box '
@@ -310,16 +313,40 @@ def main():
         else:
             dist.init_process_group('nccl', device_id=dev)
 
-    ctrl = make_controller('cart_pole_with_walls', backend='hip', device=local)
-    T, nub = ctrl.T, ctrl.mld.nub
     B = args.frontier
     if args.frontier_total > 0:
         if args.frontier_total % world:
             raise SystemExit('--frontier-total must be a multiple of the number of ranks')
         B = args.frontier_total // world
-    # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1
-    fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
-    x0_h = np.array([0., 0., 1., 0.])
+    if args.workload == 'random_mld':
+        # BASELINE configs[4]: frontier = prefixes of a dive to a feasible leaf, every other one with a flipped binary
+        from helpers import random_mld, _NoBackend
+        from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+        from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+        mld, objective, x0_h = random_mld()
+        ctrl = HybridModelPredictiveController(mld, 30, objective, None, backend=_NoBackend())
+        ctrl.qp = HipBatchedQP(ctrl.problem_data(), device=local)
+        T, nub = ctrl.T, ctrl.mld.nub
+        Cj = np.array([mld.F[52 + 4 * j] for j in range(nub)])
+        leaf = np.full((1, T * nub), -1, np.int8)
+        for t in range(T):
+            rr = ctrl.qp.solve_batch(x0_h, leaf)
+            leaf[0, t * nub:(t + 1) * nub] = (rr['primal'][0][:(T + 1) * 20].reshape(T + 1, 20)[t] @ Cj.T >= 0)
+        rng = np.random.default_rng(rank)
+        base = np.full((256, T * nub), -1, np.int8)
+        for k in range(1, 256):
+            d = int(rng.integers(1, T * nub + 1))
+            base[k, :d] = leaf[0, :d]
+            if k % 2 == 0:
+                j = int(rng.integers(0, d))
+                base[k, j] = 1 - base[k, j]
+        fix_h = np.tile(base, (B // 256 + 1, 1))[:B]
+    else:
+        ctrl = make_controller('cart_pole_with_walls', T=40 if args.workload == 'cart_pole_n40' else None, backend='hip', device=local)
+        T, nub = ctrl.T, ctrl.mld.nub
+        # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1
+        fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
+        x0_h = np.array([0., 0., 1., 0.])
     fix = torch.from_numpy(fix_h).to(dev)
     x0 = torch.from_numpy(x0_h).to(dev)
     out = dict(obj=torch.empty(B, dtype=torch.float64, device=dev), dual_obj=torch.empty(B, dtype=torch.float64, device=dev),
@@ -377,7 +404,7 @@ def main():
         # from the committed summary (profiles/collect.sh + profiles/summarise.py), valid for the default frontier
         traffic, traffic_src = None, None
         try:
-            if B == 4096 and args.p_one == 0.5:
+            if B == 4096 and args.p_one == 0.5 and args.workload == 'cart_pole_n20':
                 with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as fh:
                     traffic = json.load(fh)['hbm_traffic_bytes_per_launch']
                 traffic_src = 'profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
@@ -385,13 +412,13 @@ def main():
             pass
         polished = int(((out['iters'].cpu().numpy() >> 16) & 1).sum())
         line = {
-            'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier',
+            'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier' if args.workload == 'cart_pole_n20' else 'QP subproblems/sec, ' + args.workload,
             'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': ('strong' if args.frontier_total > 0 else 'weak') if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cart_pole_with_walls N=20, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), '
-                                   'p_one=%.2f' % args.p_one,
+            'config': {'workload': ('cart_pole_with_walls N=%d, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), p_one=%.2f' % (T, args.p_one))
+                       if args.workload != 'random_mld' else 'random MLD nx=20 nu=6+8 N=30 (SURVEY 8d C4), dive frontier',
                        'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist(), 'parallelism': 'frontier sharded by node, '
                        'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
                        'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps, active-set polish'},
@@ -409,14 +436,14 @@ def main():
             'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
                       'not_converged': int((status > 1).sum()), 'polished': polished, 'ipm_iters_mean': float(iters.mean())},
         }
-        if world == 1:
+        if world == 1 and args.workload == 'cart_pole_n20':
             try:  # second kernel of the path (HBM bound), a few milliseconds
                 line['warm_start_shift'] = shift_bandwidth(ctrl, dev)
             except Exception as e:
                 line['warm_start_shift'] = {'error': str(e)}
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
-        if world == 1 and not args.no_secondary and not args.no_cpu_baseline:
+        if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.workload == 'cart_pole_n20':
             for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, x0_h)), ('other_configs', lambda: other_configs(dev)),
                             ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl))):
                 try:

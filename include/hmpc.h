@@ -185,6 +185,20 @@ int hmpc_fleet_shift(hmpc_fleet *f, const double *e0 /* K x nx */, int32_t *cove
 /* kernel launches (rounds) and nodes sent to the QP kernel since creation */
 int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
 
+/* ---- Incumbent exchange between the GPUs of a node (RCCL over xGMI) ----------------------------------
+ * A frontier is sharded by node (node k to rank k mod nranks; nodes are independent, no data-path collective).
+ * Once per branch-and-bound round every rank calls hmpc_allreduce_incumbent with its best upper bound and its
+ * number of open candidates; on return *ub is the global best (every rank prunes against it) and *open the
+ * largest count on any rank (zero exactly when all ranks are done: they stop in the same round).  One all-reduce
+ * (MIN) of two float64.  Setup as for any RCCL communicator: rank 0 calls hmpc_comm_unique_id and hands the
+ * 128 bytes to the other ranks (the caller's transport), then every rank calls hmpc_comm_create.  RCCL is
+ * loaded at run time; a process that never creates a communicator does not need it. */
+typedef struct hmpc_comm hmpc_comm;
+int hmpc_comm_unique_id(void *id128 /* 128 bytes out */);
+int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out);
+int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub /* in/out */, int32_t *open /* in/out */);
+int hmpc_comm_destroy(hmpc_comm *c);
+
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);
 

@@ -75,3 +75,25 @@ def test_fleet_stops_a_loop_whose_miqp_is_infeasible_and_resets():
     single = ctrl.feedforward(X0, printing_period=None)
     assert abs(r3['cost'][1] - single[0].objective) < 1e-9
     assert fl.stats()['rounds'] > 0
+
+
+def test_incumbent_allreduce_through_the_c_abi():
+    # hmpc_allreduce_incumbent (include/hmpc.h): RCCL communicator of one rank on this box -- the exchange must be the
+    # identity; with N ranks the same call is MIN over (ub, -open) (warm_start_hmpc_amd/distributed.py is the tested
+    # N-rank form, gloo world size 2 in tests/test_distributed.py)
+    import ctypes
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    lib, h = ctrl.qp.lib, ctrl.qp.handle
+    uid = ctypes.create_string_buffer(128)
+    assert lib.hmpc_comm_unique_id(uid) == 0, lib.hmpc_last_error()
+    comm = ctypes.c_void_p()
+    assert lib.hmpc_comm_create(h, 1, 0, uid, ctypes.byref(comm)) == 0, lib.hmpc_last_error()
+    ub, n_open = ctypes.c_double(0.125), ctypes.c_int32(7)
+    assert lib.hmpc_allreduce_incumbent(comm, ctypes.byref(ub), ctypes.byref(n_open)) == 0, lib.hmpc_last_error()
+    assert ub.value == 0.125 and n_open.value == 7
+    ub.value = float('inf')
+    n_open.value = 0
+    assert lib.hmpc_allreduce_incumbent(comm, ctypes.byref(ub), ctypes.byref(n_open)) == 0
+    assert ub.value == float('inf') and n_open.value == 0
+    assert lib.hmpc_comm_create(h, 2, 5, uid, ctypes.byref(ctypes.c_void_p())) == -1      # rank out of range
+    assert lib.hmpc_comm_destroy(comm) == 0

@@ -1,0 +1,103 @@
+// hmpc_comm.hip -- the one collective of the path behind the C ABI: all-reduce of the incumbent over RCCL.
+//
+// The reference is single-process; sharding a frontier over the GPUs of a node is new.  Nodes are
+// independent, so the only exchange is, once per branch-and-bound round, MIN over two float64 per rank,
+// (upper bound, -open candidates): every rank then prunes against the global best and all ranks stop in the same round
+// (the Python form is warm_start_hmpc_amd/distributed.py::IncumbentExchange).  8-byte messages: latency bound on xGMI,
+// bandwidth is irrelevant.  RCCL is bound at run time (dlopen): a process that never creates a communicator does not
+// need the library, and a process that already loaded RCCL (PyTorch) shares that copy.
+#include <dlfcn.h>
+
+struct hmpc_comm {
+    hmpc_handle *h = nullptr;
+    void *lib = nullptr;
+    void *comm = nullptr; // ncclComm_t
+    double *d_pair = nullptr, *h_pair = nullptr;
+    hipStream_t stream = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+namespace {
+struct RcclId { char bytes[128]; }; // ncclUniqueId (NCCL_UNIQUE_ID_BYTES = 128), passed by value to ncclCommInitRank
+void *rccl_open()
+{
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        if (void *l = dlopen(name, RTLD_NOW | RTLD_GLOBAL)) return l;
+    }
+    return nullptr;
+}
+} // namespace
+
+extern "C" int hmpc_comm_unique_id(void *id128)
+{
+    g_err.clear();
+    if (!id128) return fail(HMPC_EINVAL, "comm: null id buffer");
+    void *lib = rccl_open();
+    if (!lib) return fail(HMPC_EDEVICE, std::string("comm: cannot load RCCL: ") + dlerror());
+    auto get = (int (*)(RcclId *))dlsym(lib, "ncclGetUniqueId");
+    if (!get) return fail(HMPC_EDEVICE, "comm: ncclGetUniqueId not found");
+    const int rc = get((RcclId *)id128);
+    return rc == 0 ? HMPC_OK : fail(HMPC_EDEVICE, "comm: ncclGetUniqueId failed");
+}
+
+extern "C" int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out)
+{
+    g_err.clear();
+    if (!h || !id128 || !out || nranks < 1 || rank < 0 || rank >= nranks) return fail(HMPC_EINVAL, "comm: bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hmpc_comm *c = new hmpc_comm();
+    c->h = h;
+    c->lib = rccl_open();
+    if (!c->lib) { delete c; return fail(HMPC_EDEVICE, "comm: cannot load RCCL"); }
+    auto init = (int (*)(void **, int, RcclId, int))dlsym(c->lib, "ncclCommInitRank");
+    c->AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(c->lib, "ncclAllReduce");
+    c->CommDestroy = (int (*)(void *))dlsym(c->lib, "ncclCommDestroy");
+    c->GetErrorString = (const char *(*)(int))dlsym(c->lib, "ncclGetErrorString");
+    if (!init || !c->AllReduce || !c->CommDestroy) { delete c; return fail(HMPC_EDEVICE, "comm: RCCL symbols not found"); }
+    RcclId id;
+    std::memcpy(id.bytes, id128, sizeof id.bytes);
+    const int rc = init(&c->comm, nranks, id, rank);
+    if (rc != 0) {
+        std::string msg = std::string("comm: ncclCommInitRank failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?");
+        delete c;
+        return fail(HMPC_EDEVICE, msg);
+    }
+    if (hipMalloc((void **)&c->d_pair, 2 * sizeof(double)) != hipSuccess || hipHostMalloc((void **)&c->h_pair, 2 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        hmpc_comm_destroy(c);
+        return fail(HMPC_EDEVICE, "comm: cannot allocate");
+    }
+    *out = c;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub, int32_t *open)
+{
+    g_err.clear();
+    if (!c || !ub || !open) return fail(HMPC_EINVAL, "comm: null argument");
+    HIPCHK(hipSetDevice(c->h->device));
+    c->h_pair[0] = *ub;
+    c->h_pair[1] = -(double)*open;
+    HIPCHK(hipMemcpyAsync(c->d_pair, c->h_pair, 2 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    const int rc = c->AllReduce(c->d_pair, c->d_pair, 2, /* ncclFloat64 */ 8, /* ncclMin */ 3, c->comm, c->stream);
+    if (rc != 0) return fail(HMPC_EDEVICE, std::string("comm: ncclAllReduce failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?"));
+    HIPCHK(hipMemcpyAsync(c->h_pair, c->d_pair, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *ub = c->h_pair[0];
+    *open = (int32_t)std::llround(-c->h_pair[1]);
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_comm_destroy(hmpc_comm *c)
+{
+    if (!c) return HMPC_OK;
+    (void)hipSetDevice(c->h->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->comm && c->CommDestroy) (void)c->CommDestroy(c->comm);
+    if (c->d_pair) (void)hipFree(c->d_pair);
+    if (c->h_pair) (void)hipHostFree(c->h_pair);
+    delete c;
+    return HMPC_OK;
+}

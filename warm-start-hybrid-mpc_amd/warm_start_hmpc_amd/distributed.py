@@ -4,9 +4,11 @@
 The reference is single-process; this layer is new.  Nodes of a frontier are
 independent QPs, so they are dealt to the ranks round-robin with no data-path collective.  The
 only exchange the path needs is the incumbent: once per round every rank contributes its best
-upper bound and its number of open candidates to ONE small all-reduce (two float64: min is
-taken of (ub, -open) packed as (ub, -open) -> MIN gives ub; the count uses a second SUM), so
-that every rank prunes against the global best and all ranks stop together.
+upper bound and its number of open candidates to ONE small all-reduce -- MIN over the two
+float64 (ub, -open): the first entry is the global upper bound, minus the second the LARGEST
+number of open candidates on any rank, zero exactly when every rank is done -- so that every
+rank prunes against the global best and all ranks stop together.  The same exchange is offered
+to non-Python callers of the library as ``hmpc_allreduce_incumbent`` (include/hmpc.h, RCCL).
 """
 import numpy as np
 
@@ -29,12 +31,11 @@ class IncumbentExchange(object):
 
     def __call__(self, ub, n_candidates):
         torch, dist = self.torch, self.dist
-        lo = torch.tensor([ub], dtype=torch.float64, device=self.device)
-        cnt = torch.tensor([float(n_candidates)], dtype=torch.float64, device=self.device)
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=self.group)
+        pair = torch.tensor([ub, -float(n_candidates)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(pair, op=dist.ReduceOp.MIN, group=self.group)
         self.rounds += 1
-        return float(lo.item()), int(cnt.item())
+        ub_all, open_max = pair.tolist()          # (the search only asks whether ANY rank still has candidates)
+        return float(ub_all), int(round(-open_max))
 
 
 def solve_frontier_sharded(ctrl, fix, x0, group=None, device=None):

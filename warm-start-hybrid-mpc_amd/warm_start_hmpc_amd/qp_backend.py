@@ -87,6 +87,14 @@ def load_library():
         lib.hmpc_fleet_shift.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.hmpc_fleet_stats.restype = ctypes.c_int
         lib.hmpc_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.hmpc_comm_unique_id.restype = ctypes.c_int
+        lib.hmpc_comm_unique_id.argtypes = [ctypes.c_void_p]
+        lib.hmpc_comm_create.restype = ctypes.c_int
+        lib.hmpc_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.hmpc_allreduce_incumbent.restype = ctypes.c_int
+        lib.hmpc_allreduce_incumbent.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
+        lib.hmpc_comm_destroy.restype = ctypes.c_int
+        lib.hmpc_comm_destroy.argtypes = [ctypes.c_void_p]
         _lib = lib
     return _lib
 
@@ -95,7 +103,7 @@ EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_la
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats')
+                    'hmpc_fleet_stats', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_comm_destroy')
 
 
 class HipBatchedQP(object):
