@@ -6,7 +6,7 @@
 // warm_start_hmpc_amd/batched.py::construct_warm_start and controller.py::_pi_sum, against which
 // tests/test_gpu_parity.py checks this kernel.
 //
-// One wavefront per leaf, four per workgroup; the workgroup stages the node-independent maps in LDS once and then
+// One wavefront per leaf, SHIFT_WAVES per workgroup; the workgroup stages the node-independent maps in LDS once and then
 // walks its share of the leaves.  The work per leaf is a strided copy of the row (everything moves one stage
 // towards the present), two small matrix-vector products for the stage that enters at the end of
 // the horizon, and a handful of dot products for the change of the dual objective: ~8 KB read and
@@ -36,7 +36,15 @@ static __device__ __forceinline__ double shift_wave_sum(double v)
 }
 
 // Waves per workgroup: the workgroup stages the maps once and every wave shifts one leaf at a time.
-#define SHIFT_WAVES 8
+// Measured on MI355X (65 536 leaves): 8 waves per workgroup at the compiler's 163 registers -> one workgroup per CU,
+// 2.12 TB/s; 4 waves per workgroup held to 128 registers (4 waves per SIMD, 4 workgroups per CU) -> 2.55 TB/s;
+// 5 or more waves per SIMD spill and lose (1.7 TB/s and below).
+#ifndef SHIFT_WAVES
+#define SHIFT_WAVES 4
+#endif
+#ifndef HMPC_SHIFT_ATTR
+#define HMPC_SHIFT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#endif
 
 // LDS doubles the kernel needs (the host checks this against the CU's LDS; larger problems read the maps in place).
 static inline size_t hmpc_shift_lds_doubles(const DevProb &p, bool staged)
@@ -48,7 +56,7 @@ static inline size_t hmpc_shift_lds_doubles(const DevProb &p, bool staged)
 }
 
 template <bool STAGED>
-__global__ void __launch_bounds__(64 * SHIFT_WAVES) hmpc_shift_kernel(const DevProb p, const ShiftArgs a)
+__global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_kernel(const DevProb p, const ShiftArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
