@@ -109,7 +109,9 @@ typedef struct hmpc_result {
 typedef struct hmpc_handle hmpc_handle;
 
 /* Copies the problem to the device, precomputes scalings and sparse row/column lists.
- * options may be NULL (defaults).  The handle is bound to one device and is not thread-safe. */
+ * options may be NULL (defaults).  The handle is bound to one device and is not thread-safe; it owns one set of
+ * device workspaces: at most ONE launch per handle may be in flight (the device-pointer forms are asynchronous --
+ * synchronise the stream, or use one handle per stream, before launching on the same handle again). */
 int hmpc_create(const hmpc_problem *problem, const hmpc_options *options, hmpc_handle **out);
 int hmpc_destroy(hmpc_handle *h);
 

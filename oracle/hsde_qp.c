@@ -625,6 +625,8 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
                 for (int i = 0; i < T * nub; i++) k->nuf[i] -= last_alpha * k->nuf2[i];
                 for (int r = 0; r < M; r++) if (k->act[r]) { k->z[r] -= last_alpha * k->z2[r]; k->s[r] -= last_alpha * k->rhs_c[r]; }
                 tau -= last_alpha * last_dtau; kap -= last_alpha * last_dkap;
+                for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
+                for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
                 break;
             }
         }

@@ -50,8 +50,8 @@ struct hmpc_handle {
     size_t lds = 0;
     int max_grid = 0, last_grid = 0;
     // staging for the host-pointer entry point
-    void *d_x0 = nullptr, *d_fix = nullptr, *d_obj = nullptr, *d_dobj = nullptr, *d_status = nullptr,
-         *d_iters = nullptr, *d_primal = nullptr, *d_dual = nullptr;
+    void *d_x0 = nullptr;    // one device block (inputs, then outputs: stage_layout)
+    void *h_stage = nullptr; // its pinned host mirror
     int staged = 0;
 };
 
@@ -375,8 +375,8 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->rows_ws) (void)hipFree(h->rows_ws);
     if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->trace) (void)hipFree(h->trace);
-    for (void *d : {h->d_x0, h->d_fix, h->d_obj, h->d_dobj, h->d_status, h->d_iters, h->d_primal, h->d_dual})
-        if (d) (void)hipFree(d);
+    if (h->d_x0) (void)hipFree(h->d_x0);
+    if (h->h_stage) (void)hipHostFree(h->h_stage);
     delete h;
     return HMPC_OK;
 }
@@ -395,6 +395,16 @@ extern "C" int hmpc_set_shift_maps(hmpc_handle *h, const hmpc_shift_maps *m)
     if (!h || !m || !m->M_mu || !m->M_rho || !m->V) return fail(HMPC_EINVAL, "null argument");
     HIPCHK(hipSetDevice(h->device));
     DevProb &p = h->dp;
+    // the retain rule of the shift kernel reads one binary per lane of a wavefront
+    if (p.nub > 64) return fail(HMPC_EINVAL, "the node shift supports at most 64 binaries per stage");
+    // a second call replaces the maps (the previous device copies are released)
+    for (const double *old : {p.shift_Mmu, p.shift_Mrho, p.shift_V})
+        if (old) {
+            for (auto it = h->allocs.begin(); it != h->allocs.end(); ++it)
+                if (*it == (void *)old) { h->allocs.erase(it); break; }
+            (void)hipFree((void *)old);
+        }
+    p.shift_Mmu = p.shift_Mrho = p.shift_V = nullptr;
     int rc;
     auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
     if ((rc = upload(h, vec(m->M_mu, (size_t)p.nc * p.ncL), &p.shift_Mmu))) return rc;
@@ -528,22 +538,40 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     return HMPC_OK;
 }
 
+// Staging of the host-pointer entry point: ONE device block and ONE pinned host block, inputs first, then the outputs in
+// the order obj | dual_obj | status | iters | primal | dual -- one copy up, one copy down per call (round 1: two pageable
+// copies up, six down, each its own synchronisation: ~100 us of a 1.4 ms branch-and-bound round).
+struct StageLayout {
+    size_t x0, fix, obj, dobj, status, iters, primal, dual, in_bytes, total;
+};
+static StageLayout stage_layout(const DevProb &p, size_t B)
+{
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    StageLayout L;
+    L.x0 = 0;
+    L.fix = up(B * p.nx * sizeof(double));
+    L.in_bytes = L.fix + up(B * (size_t)p.T * p.nub + 1);
+    L.obj = L.in_bytes;
+    L.dobj = L.obj + up(B * sizeof(double));
+    L.status = L.dobj + up(B * sizeof(double));
+    L.iters = L.status + up(B * sizeof(int32_t));
+    L.primal = L.iters + up(B * sizeof(int32_t));
+    L.dual = L.primal + up(B * (size_t)p.n_primal * sizeof(double));
+    L.total = L.dual + up(B * (size_t)p.n_dual * sizeof(double));
+    return L;
+}
+
 static int ensure_staging(hmpc_handle *h, int B)
 {
     if (B <= h->staged) return HMPC_OK;
-    for (void **d : {&h->d_x0, &h->d_fix, &h->d_obj, &h->d_dobj, &h->d_status, &h->d_iters, &h->d_primal, &h->d_dual})
-        if (*d) { (void)hipFree(*d); *d = nullptr; }
+    if (h->d_x0) { (void)hipFree(h->d_x0); h->d_x0 = nullptr; }
+    if (h->h_stage) { (void)hipHostFree(h->h_stage); h->h_stage = nullptr; }
     h->staged = 0;
-    const DevProb &p = h->dp;
-    HIPCHK(hipMalloc(&h->d_x0, (size_t)B * p.nx * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_fix, (size_t)B * p.T * p.nub + 1));
-    HIPCHK(hipMalloc(&h->d_obj, (size_t)B * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_dobj, (size_t)B * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_status, (size_t)B * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&h->d_iters, (size_t)B * sizeof(int32_t)));
-    HIPCHK(hipMalloc(&h->d_primal, (size_t)B * p.n_primal * sizeof(double)));
-    HIPCHK(hipMalloc(&h->d_dual, (size_t)B * p.n_dual * sizeof(double)));
-    h->staged = B;
+    const int cap = B < 64 ? 64 : B + B / 4;
+    const StageLayout L = stage_layout(h->dp, (size_t)cap);
+    HIPCHK(hipMalloc(&h->d_x0, L.total));
+    HIPCHK(hipHostMalloc(&h->h_stage, L.total, hipHostMallocDefault));
+    h->staged = cap;
     return HMPC_OK;
 }
 
@@ -558,24 +586,37 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     const DevProb &p = h->dp;
     int rc = ensure_staging(h, B);
     if (rc) return rc;
-    if (x0_stride == 0) {
-        HIPCHK(hipMemcpy(h->d_x0, x0, p.nx * sizeof(double), hipMemcpyHostToDevice));
-    } else {
-        HIPCHK(hipMemcpy2D(h->d_x0, p.nx * sizeof(double), x0, x0_stride * sizeof(double), p.nx * sizeof(double), B,
-                           hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(h->d_fix, fix, (size_t)B * p.T * p.nub, hipMemcpyHostToDevice));
-    hmpc_result d{(double *)h->d_obj, (double *)h->d_dobj, (int32_t *)h->d_status, (int32_t *)h->d_iters,
-                  out->primal ? (double *)h->d_primal : nullptr, out->dual ? (double *)h->d_dual : nullptr};
-    rc = hmpc_solve_batch_device(h, (const double *)h->d_x0, x0_stride == 0 ? 0 : p.nx, (const int8_t *)h->d_fix, B, &d, nullptr);
+    const StageLayout L = stage_layout(p, (size_t)h->staged);
+    char *hs = (char *)h->h_stage, *ds = (char *)h->d_x0;
+    const size_t nfix = (size_t)p.T * p.nub;
+    if (x0_stride == 0) std::memcpy(hs + L.x0, x0, p.nx * sizeof(double));
+    else
+        for (int b = 0; b < B; b++) std::memcpy(hs + L.x0 + (size_t)b * p.nx * sizeof(double), x0 + (size_t)b * x0_stride, p.nx * sizeof(double));
+    std::memcpy(hs + L.fix, fix, (size_t)B * nfix);
+    HIPCHK(hipMemcpyAsync(ds, hs, L.in_bytes, hipMemcpyHostToDevice, nullptr));
+    hmpc_result d{(double *)(ds + L.obj), (double *)(ds + L.dobj), (int32_t *)(ds + L.status), (int32_t *)(ds + L.iters),
+                  out->primal ? (double *)(ds + L.primal) : nullptr, out->dual ? (double *)(ds + L.dual) : nullptr};
+    rc = hmpc_solve_batch_device(h, (const double *)(ds + L.x0), x0_stride == 0 ? 0 : p.nx, (const int8_t *)(ds + L.fix), B, &d, nullptr);
     if (rc) return rc;
-    HIPCHK(hipDeviceSynchronize());
-    if (out->obj) HIPCHK(hipMemcpy(out->obj, h->d_obj, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->dual_obj) HIPCHK(hipMemcpy(out->dual_obj, h->d_dobj, (size_t)B * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->status) HIPCHK(hipMemcpy(out->status, h->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out->iters) HIPCHK(hipMemcpy(out->iters, h->d_iters, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (out->primal) HIPCHK(hipMemcpy(out->primal, h->d_primal, (size_t)B * p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->dual) HIPCHK(hipMemcpy(out->dual, h->d_dual, (size_t)B * p.n_dual * sizeof(double), hipMemcpyDeviceToHost));
+    // small outputs in one copy through the pinned block; large primal / dual blocks straight into the caller's arrays
+    // (a pageable copy is pipelined by the runtime, a detour through the staging block would not be)
+    const size_t pbytes = (size_t)B * p.n_primal * sizeof(double), dbytes = (size_t)B * p.n_dual * sizeof(double);
+    const bool big = pbytes + dbytes > (size_t)4 << 20;
+    const size_t small_end = big ? L.primal : (out->dual ? L.dual + dbytes : out->primal ? L.primal + pbytes : L.primal);
+    HIPCHK(hipMemcpyAsync(hs + L.obj, ds + L.obj, small_end - L.obj, hipMemcpyDeviceToHost, nullptr));
+    if (big) {
+        if (out->primal) HIPCHK(hipMemcpyAsync(out->primal, ds + L.primal, pbytes, hipMemcpyDeviceToHost, nullptr));
+        if (out->dual) HIPCHK(hipMemcpyAsync(out->dual, ds + L.dual, dbytes, hipMemcpyDeviceToHost, nullptr));
+    }
+    HIPCHK(hipStreamSynchronize(nullptr));
+    if (out->obj) std::memcpy(out->obj, hs + L.obj, (size_t)B * sizeof(double));
+    if (out->dual_obj) std::memcpy(out->dual_obj, hs + L.dobj, (size_t)B * sizeof(double));
+    if (out->status) std::memcpy(out->status, hs + L.status, (size_t)B * sizeof(int32_t));
+    if (out->iters) std::memcpy(out->iters, hs + L.iters, (size_t)B * sizeof(int32_t));
+    if (!big) {
+        if (out->primal) std::memcpy(out->primal, hs + L.primal, pbytes);
+        if (out->dual) std::memcpy(out->dual, hs + L.dual, dbytes);
+    }
     if (h->trace) {
         std::vector<double> tr(2 * 64 * 8 + 32);
         (void)hipMemcpy(tr.data(), h->trace, tr.size() * sizeof(double), hipMemcpyDeviceToHost);

@@ -1727,6 +1727,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 tau -= last_alpha * last_dtau;
                 kap -= last_alpha * last_dkap;
                 __syncthreads();
+                set_prescribed<D>(p, S, lane, tau); // x_0 and the fixed binaries follow tau exactly, also after the way back
+                __syncthreads();
                 break;
             }
         }

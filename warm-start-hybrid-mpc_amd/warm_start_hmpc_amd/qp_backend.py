@@ -145,7 +145,7 @@ class HipBatchedQP(object):
         n_primal, n_dual = ctypes.c_int32(), ctypes.c_int32()
         self.lib.hmpc_record_sizes(self.handle, ctypes.byref(n_primal), ctypes.byref(n_dual))
         self.n_primal, self.n_dual = n_primal.value, n_dual.value
-        self.nx, self.nu, self.nfix = nx, nu, T * nub
+        self.nx, self.nu, self.nfix, self._T = nx, nu, T * nub, T
         self._shift_ready = False
 
     def __del__(self):
@@ -215,6 +215,11 @@ class HipBatchedQP(object):
         """Uploads the node-independent maps of the shift: mu'_{T-2} = M_mu mu_{T-1}, rho'_{T-1} = M_rho rho_T
         (``controller._update``) and the binary selector ``mld.V``."""
         keep = [np.ascontiguousarray(np.atleast_2d(a), dtype=np.float64) for a in (M_mu, M_rho, V)]
+        k = self._keep
+        want = ((k['h'].size, k['h_Tm1'].size), (k['Q'].shape[0], k['Q_T'].shape[0]), (self.nfix // self._T, self.nu))
+        for name, a, shp in zip(('M_mu', 'M_rho', 'V'), keep, want):
+            if a.shape != shp:      # the library reads exactly these sizes from the host pointers
+                raise ValueError('Matrix %s has shape %s, expected %s.' % (name, a.shape, shp))
         m = _ShiftMaps(*[a.ctypes.data_as(_dp) for a in keep])
         self._check(self.lib.hmpc_set_shift_maps(self.handle, ctypes.byref(m)))
         self._shift_ready = True
