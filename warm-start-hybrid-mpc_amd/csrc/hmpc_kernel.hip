@@ -153,6 +153,27 @@ DEV double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+// Broadcast inside the first row of 16 lanes (source and readers in lanes 0..15) as ONE instruction: the 64-bit DPP move
+// v_mov_b64_dpp row_newbcast:src.  The stage vectors of the compile-time shapes have nz <= 16 components on lanes
+// 0 .. nz-1, so every broadcast of their recursions is of this kind; against the v_readlane pair it halves the instruction
+// count of a broadcast, keeps the value in a VGPR (no VALU -> SGPR -> VALU hazard) and frees ~30 SGPRs that otherwise
+// spill.  Lanes of the other rows read lane src of THEIR row: they hold no component, their values are never read.
+// src must be a constant after unrolling (the DPP control is an immediate): the switch then folds to one case.
+template <class D> DEV double bcast16(double v, int src)
+{
+    if constexpr (!D::kDpp) return bcast(v, src);
+    const long x = __builtin_bit_cast(long, v);
+    long r;
+    switch (src) {
+#define HMPC_DPP_CASE(n) case n: r = __builtin_amdgcn_update_dpp((long)0, x, 0x150 + n, 0xf, 0xf, false); break;
+        HMPC_DPP_CASE(0) HMPC_DPP_CASE(1) HMPC_DPP_CASE(2) HMPC_DPP_CASE(3) HMPC_DPP_CASE(4) HMPC_DPP_CASE(5) HMPC_DPP_CASE(6) HMPC_DPP_CASE(7)
+        HMPC_DPP_CASE(8) HMPC_DPP_CASE(9) HMPC_DPP_CASE(10) HMPC_DPP_CASE(11) HMPC_DPP_CASE(12) HMPC_DPP_CASE(13) HMPC_DPP_CASE(14)
+#undef HMPC_DPP_CASE
+    default: r = __builtin_amdgcn_update_dpp((long)0, x, 0x150 + 15, 0xf, 0xf, false); break;
+    }
+    return __builtin_bit_cast(double, r);
+}
+
 // Reciprocal to ~1 ulp: v_rcp_f64 (measured on MI355X: 4.5e-8 relative) and two Newton steps (2e-15, then
 // rounding level).  The row loops divide by slacks and multipliers a dozen times per row and iteration;
 // the IEEE division sequence is three times as long and its last-bit guarantees buy nothing there.
@@ -205,8 +226,12 @@ struct Lds {
 
 // Problem dimensions: compile-time for the instantiated shapes (index arithmetic folds to
 // immediates, inner loops unroll, divisions become multiplies), run-time for the generic kernel.
-template <int NX_, int NU_, int NUB_, int NW_>
+template <int NX_, int NU_, int NUB_, int NW_, bool DPP_ = false>
 struct Dims {
+    // broadcasts of the register recursions as DPP row moves (bcast16) or v_readlane pairs: the DPP form keeps the
+    // broadcast values in VGPRs and pays where the row state leaves room (kernels with few row slots: the 2- and
+    // 4-wave variants, -10 % latency per launch); with 15 slots per lane (1 wave per node) it spills (336 B per lane)
+    static constexpr bool kDpp = DPP_;
     static constexpr int kNX = NX_, kNU = NU_, kNUB = NUB_;
     static constexpr int kNW = NW_, kNT = NW_ * 64; // waves / threads per node (workgroup)
     // NX_ < 0: the generic kernel with the stage lists and the Riccati factor (multipliers, cost-to-go) in
@@ -841,6 +866,7 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
 template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
+    static_assert(NZ <= 16, "the register recursions broadcast inside one row of 16 lanes");
     constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU), KG = D::kKC, GH = KG / 2;
     const int T = p.T;
     FSTAMP_DECL;
@@ -928,7 +954,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             for (int i = 0; i < NX; i++) {
                 double a = 0.0;
 #pragma unroll
-                for (int l = 0; l < NX; l++) a += bcast(pn[l < i ? l : i], l < i ? i : l) * ABc[l]; // P_{t+1}(i, l), symmetric
+                for (int l = 0; l < NX; l++) a += bcast16<D>(pn[l < i ? l : i], l < i ? i : l) * ABc[l]; // P_{t+1}(i, l), symmetric
                 y[i] = a;
             }
             double col[NZ];
@@ -936,7 +962,8 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             for (int i = 0; i < NZ; i++) {
                 double a = 0.0;
 #pragma unroll
-                for (int l = 0; l < NX; l++) a += bcast(ABc[l], i) * y[l];
+                for (int l = 0; l < NX; l++) a += S.AB[l * NZ + i] * y[l]; // (a uniform LDS read: as a cross-lane broadcast the 44
+                                                                         // constants are hoisted out of every loop and live in registers for good)
                 col[i] = a;
             }
             FSTAMP(0);
@@ -965,7 +992,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 for (int b = 0; b < NUB; b++)
                     if (fxv[b] == 1) {
 #pragma unroll
-                        for (int i = 0; i < NZ; i++) mbv[i] += bcast(col[i], NX + NUC + b);
+                        for (int i = 0; i < NZ; i++) mbv[i] += bcast16<D>(col[i], NX + NUC + b);
                     }
                 if (lane == 0) {
 #pragma unroll
@@ -988,7 +1015,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             double myrow[NU], dinv[NU];
             auto pivot = [&](const int j) {
                 const int pj = NX + j;
-                const double d = bcast(col[pj], pj); // 1 at a prescribed pivot: the step below changes nothing
+                const double d = bcast16<D>(col[pj], pj); // 1 at a prescribed pivot: the step below changes nothing
                 if (!(d > 0.0)) bad = 1;
                 double rinv = __builtin_amdgcn_rcp(d);
                 rinv = rinv * (2.0 - d * rinv);
@@ -997,7 +1024,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 myrow[j] = (lane < NX || lane > pj) ? cr : 0.0;
 #pragma unroll
                 for (int i = 0; i < NZ; i++) {
-                    if (i < NX || i > pj) col[i] -= bcast(col[i], pj) * cr; // rows still to be reduced
+                    if (i < NX || i > pj) col[i] -= bcast16<D>(col[i], pj) * cr; // rows still to be reduced
                 }
             };
 #pragma unroll
@@ -1390,14 +1417,14 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
             }
             double v = mpre;
 #pragma unroll
-            for (int l = 0; l < NX; l++) v += ABcol[l] * bcast(qv, l);
+            for (int l = 0; l < NX; l++) v += ABcol[l] * bcast16<D>(qv, l);
             if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
             // forward substitution: the factorisation's row operations applied to the vector
 #pragma unroll
-            for (int j = 0; j < NUC; j++) v -= mrow[j] * bcast(v, NX + j);
+            for (int j = 0; j < NUC; j++) v -= mrow[j] * bcast16<D>(v, NX + j);
             if (!((S.fullfix >> t) & 1ull)) { // the binaries' steps are no-ops (zero multipliers) when all are fixed
 #pragma unroll
-                for (int j = NUC; j < NU; j++) v -= mrow[j] * bcast(v, NX + j);
+                for (int j = NUC; j < NU; j++) v -= mrow[j] * bcast16<D>(v, NX + j);
             }
             if (lane >= NX && lane < NZ) dw[t * NZ + lane] = v; // y = L_u^{-1} m_u, parked in the input slots
             pvr = v;                                            // lanes < NX: p_t
@@ -1447,14 +1474,14 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
             }
 #pragma unroll
             for (int l = 0; l < NX; l++) {
-                const double xl = bcast(xr, l);
+                const double xl = bcast16<D>(xr, l);
                 cur += lx[l] * xl;
                 xn += ABrow[l] * xl;
             }
             // back substitution with L_u' ; u_j = -(value of lane j once its turn has come)
 #pragma unroll
             for (int j = NU - 1; j >= 0; j--) {
-                const double uj = bcast(cur, j);
+                const double uj = bcast16<D>(cur, j);
                 cur -= lcol[j] * uj; // only lanes i < j hold a nonzero (j, i) entry
                 xn -= ABrow[NX + j] * uj;
             }
@@ -2211,8 +2238,8 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef Dims<NX_, NU_, NUB_, NW> D;
     constexpr int RS = KF + KB + KT;
+    typedef Dims<NX_, NU_, NUB_, NW, (RS > 0 && RS <= 8)> D;
     static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernels the lists");
     typedef typename std::conditional<(NX_ > 0), RowMapS<D, KF, KB, KT>, RowMapL<D>>::type RM;
     const int lane = threadIdx.x; // thread of the workgroup; wave 0 (lane < 64) runs the recursions

@@ -15,7 +15,8 @@ import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(os.path.dirname(_HERE), 'libhmpc.so')
+# HMPC_LIBRARY_NAME selects a build variant next to the default one (diagnostic builds: libhmpc_stamps.so, A/B timing)
+LIBRARY_PATH = os.path.join(os.path.dirname(_HERE), os.environ.get('HMPC_LIBRARY_NAME', 'libhmpc.so'))
 
 STATUS_OPTIMAL, STATUS_INFEASIBLE, STATUS_MAXITER, STATUS_NUMERICAL = 0, 1, 2, 3
 
