@@ -44,6 +44,8 @@ struct hmpc_handle {
     DevProb dp{};
     std::vector<void *> allocs;
     double *rows_ws = nullptr;
+    int32_t *order = nullptr; // processing order of large frontiers (hmpc_order_kernel)
+    int order_cap = 0;
     void *d_shift = nullptr; // staging of the host-pointer shift
     size_t shift_staged = 0;
     double *trace = nullptr;
@@ -373,6 +375,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     (void)hipSetDevice(h->device);
     for (void *d : h->allocs) (void)hipFree(d);
     if (h->rows_ws) (void)hipFree(h->rows_ws);
+    if (h->order) (void)hipFree(h->order);
     if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->trace) (void)hipFree(h->trace);
     if (h->d_x0) (void)hipFree(h->d_x0);
@@ -532,8 +535,22 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     h->lds = cf.lds;
     // (every launch: also a launch with B <= grid reads the counter once per workgroup, and what it reads must be >= 0)
     HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), (hipStream_t)stream));
+    // more nodes than resident workgroups: hand them out shallow first (hmpc_order_kernel)
+    int32_t *order = nullptr;
+    if (B >= 2 * grid && !getenv("HMPC_NO_ORDER")) {
+        if (B > h->order_cap) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            if (h->order) (void)hipFree(h->order);
+            h->order = nullptr;
+            h->order_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->order, (size_t)(B + B / 2) * sizeof(int32_t)));
+            h->order_cap = B + B / 2;
+        }
+        order = h->order;
+        hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order);
+    }
     hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
-                       d_fix, B, o, h->rows_ws, h->trace);
+                       d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order);
     HIPCHK(hipGetLastError());
     return HMPC_OK;
 }

@@ -2235,7 +2235,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
 template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW>
 __global__ void __launch_bounds__(NW * WAVE) HMPC_KERNEL_ATTR
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
-               const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace)
+               const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace, const int32_t *__restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = KF + KB + KT;
@@ -2328,7 +2328,11 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     // first gridDim.x nodes go to the workgroups by index, every further node to the first workgroup that is free
     // (one atomic per node on a counter the host zeroes before the launch).  A record does not depend on the
     // workgroup that computes it.
-    for (int qp = blockIdx.x; qp < B;) {
+    for (int slot = blockIdx.x; slot < B;) {
+        // `order` (optional): the nodes sorted by the number of fixed binaries, shallow first -- shallow nodes take more
+        // iterations (correlation -0.5 .. -0.75 on random frontiers), and with ~4 nodes per workgroup handing out the
+        // long ones first shortens the tail of a launch
+        const int qp = order ? order[slot] : slot;
         __syncthreads();
         for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
         for (int i = lane; i < nx; i += D::kNT) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
@@ -2370,15 +2374,37 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0);
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
-        qp = S.flag[1];
+        slot = S.flag[1];
     }
+}
+
+// Processing order of a large frontier: counting sort of the nodes by their number of fixed binaries (one workgroup;
+// the order inside a bucket is whatever the atomics give -- a record does not depend on when its node is solved).
+__global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restrict__ fixg, int B, int nfix, int32_t *__restrict__ order)
+{
+    __shared__ int bins[1025];
+    const int nb = nfix + 1 < 1024 ? nfix + 1 : 1024;
+    for (int i = threadIdx.x; i <= nb; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    auto bucket = [&](int b) {
+        const int8_t *f = fixg + (size_t)b * nfix;
+        int d = 0;
+        for (int i = 0; i < nfix; i++) d += f[i] >= 0;
+        return nfix + 1 <= 1024 ? d : (int)((long long)d * 1023 / nfix);
+    };
+    for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&bins[bucket(b) + 1], 1);
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int i = 1; i <= nb; i++) bins[i] += bins[i - 1]; // bins[k] = first slot of bucket k
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&bins[bucket(b)], 1)] = b;
 }
 
 #ifndef HMPC_KERNEL_ONLY // (defined by the one-instantiation probe used to inspect the generated code)
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
 // nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries), with the
 // row slots of their horizons and 1 / 2 / 4 waves per node, and the generic run-time-sized kernel.
-typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *);
+typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *, const int32_t *);
 struct hmpc_kernel_choice {
     hmpc_kernel_t fn;
     int waves;

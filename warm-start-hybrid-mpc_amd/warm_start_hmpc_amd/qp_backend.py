@@ -51,6 +51,13 @@ def load_library():
     """Loads libhmpc.so once; raises if it has not been built (``__graft_entry__.build()``)."""
     global _lib
     if _lib is None:
+        # A process has ONE HIP runtime: the first libamdhip64 loaded wins the soname.  PyTorch-ROCm ships its own copy;
+        # if this library pulled in the system one first, a later torch.cuda initialisation finds "No HIP GPUs".  So
+        # torch -- when it is installed -- goes first (it is what the device-pointer entry points are used with).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIBRARY_PATH):
             raise RuntimeError('HIP library %s not found: build it with __graft_entry__.build() '
                                '(make -C warm-start-hybrid-mpc_amd/csrc). There is no CPU fallback.' % LIBRARY_PATH)
