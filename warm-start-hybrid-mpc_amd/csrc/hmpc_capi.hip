@@ -537,7 +537,7 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), (hipStream_t)stream));
     // more nodes than resident workgroups: hand them out shallow first (hmpc_order_kernel)
     int32_t *order = nullptr;
-    if (B >= 2 * grid && !getenv("HMPC_NO_ORDER")) {
+    if (B > grid + grid / 8 && !getenv("HMPC_NO_ORDER")) {
         if (B > h->order_cap) {
             HIPCHK(hipStreamSynchronize((hipStream_t)stream));
             if (h->order) (void)hipFree(h->order);

@@ -1783,19 +1783,23 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         LANE_OPAQUE(lane);
         __syncthreads(); // every thread is done reading z from S.e
         if (polish) {
+            // active: z > s, or -- Tapia indicators over the last step (dz and ds are still in place) -- the slack
+            // shrinks faster than the multiplier: s+/s < z+/z; this reads weakly active rows right far more often than
+            // z > s alone (2.2 instead of 3.3 active sets per polish).  Decided in a pass of its own (one bit per
+            // slot): folded into the pass below it kept four values per slot alive across the row products.
+            unsigned long long amask = 0;
+            if (last_alpha > 0) {
+                ROWS_BEGIN(k, rw)
+                    const double zr = R.z(k, rw.e), sr = R.s(k, rw.e);
+                    const double sp = sr - last_alpha * R.prod(k, rw.e), zp = zr - last_alpha * R.dz(k, rw.e);
+                    if (sp > 0 && zp > 0 && zr * sp > sr * zp) amask |= 1ull << (k & 63);
+                ROWS_END
+            }
             ROWS_BEGIN(k, rw)
                 const double zr = R.z(k, rw.e); // zero on rows that take no part in this solve
                 double d = 0.0;
                 if (zr != 0.0) {
-                    // active: z > s, or -- Tapia indicators over the last step (dz and ds are still in place) -- the
-                    // slack shrinks faster than the multiplier: s+/s < z+/z; this reads weakly active rows right far
-                    // more often than z > s alone (2.2 instead of 3.3 active sets per polish)
-                    const double sr = R.s(k, rw.e);
-                    bool active = zr > sr;
-                    if (last_alpha > 0) {
-                        const double sp = sr - last_alpha * R.prod(k, rw.e), zp = zr - last_alpha * R.dz(k, rw.e);
-                        if (sp > 0 && zp > 0 && zr * sp > sr * zp) active = true;
-                    }
+                    const bool active = zr > R.s(k, rw.e) || ((amask >> (k & 63)) & 1ull);
                     R.prod(k, rw.e) = zr; // kept for the way back
                     if (active) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
                     else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
@@ -2386,18 +2390,46 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
     const int nb = nfix + 1 < 1024 ? nfix + 1 : 1024;
     for (int i = threadIdx.x; i <= nb; i += blockDim.x) bins[i] = 0;
     __syncthreads();
+    const bool words = (nfix & 3) == 0 && ((size_t)fixg & 3) == 0;
     auto bucket = [&](int b) {
         const int8_t *f = fixg + (size_t)b * nfix;
         int d = 0;
-        for (int i = 0; i < nfix; i++) d += f[i] >= 0;
+        if (words) { // four entries per load: an entry is fixed iff its sign bit is clear
+            const unsigned *w = (const unsigned *)f;
+            for (int i = 0; i < nfix / 4; i++) d += __popc(~w[i] & 0x80808080u);
+        } else {
+            for (int i = 0; i < nfix; i++) d += f[i] >= 0;
+        }
         return nfix + 1 <= 1024 ? d : (int)((long long)d * 1023 / nfix);
     };
-    for (int b = threadIdx.x; b < B; b += blockDim.x) atomicAdd(&bins[bucket(b) + 1], 1);
+    int mine[8]; // buckets of this thread's first 8 nodes (8192 nodes per launch), kept between the two passes
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const int b = threadIdx.x + q * 1024;
+        mine[q] = b < B ? bucket(b) : -1;
+        if (mine[q] >= 0) atomicAdd(&bins[mine[q] + 1], 1);
+    }
+    for (int b = threadIdx.x + 8 * 1024; b < B; b += 1024) atomicAdd(&bins[bucket(b) + 1], 1);
     __syncthreads();
-    if (threadIdx.x == 0)
-        for (int i = 1; i <= nb; i++) bins[i] += bins[i - 1]; // bins[k] = first slot of bucket k
+    if (threadIdx.x < 64) { // exclusive scan by one wave: bins[k] = first slot of bucket k
+        int carry = 0;
+        for (int base = 0; base < nb; base += 64) {
+            const int i = base + threadIdx.x + 1;
+            int v = i <= nb ? bins[i] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int u = __shfl_up(v, o);
+                if ((int)threadIdx.x >= o) v += u;
+            }
+            if (i <= nb) bins[i] = v + carry;
+            carry += __shfl(v, 63);
+        }
+    }
     __syncthreads();
-    for (int b = threadIdx.x; b < B; b += blockDim.x) order[atomicAdd(&bins[bucket(b)], 1)] = b;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+        if (mine[q] >= 0) order[atomicAdd(&bins[mine[q]], 1)] = threadIdx.x + q * 1024;
+    for (int b = threadIdx.x + 8 * 1024; b < B; b += 1024) order[atomicAdd(&bins[bucket(b)], 1)] = b;
 }
 
 #ifndef HMPC_KERNEL_ONLY // (defined by the one-instantiation probe used to inspect the generated code)
@@ -2424,7 +2456,7 @@ static int hmpc_waves_for(int B, int resident_nodes)
         if (nw == 1 || nw == 2 || nw == 4) return nw;
     }
     if (B <= resident_nodes / 4) return 4;
-    if (B <= resident_nodes / 2) return 2;
+    if (B <= resident_nodes * 3 / 4) return 2; // (round 2, DPP broadcasts: 768 nodes 3.19 ms with 2 waves, 3.37 with 1)
     return 1;
 }
 // Slots the static row map needs for this problem with nw waves per node (see RowMapS).
