@@ -453,7 +453,12 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
             else { k->D[q] = POLISH_DELTA; zk[q] = 0; }
         }
     }
-    const double ez = 1e-9 * (1 + zinf), es = 1e-9 * (1 + winf);
+    /* A violated inactive row costs its violation in x; a negative multiplier that is clipped costs |z| / (curvature
+     * of the stage cost) -- 1e-9 / 1.4e-4 would already be 7e-6 in the trajectory.  So the sign test is absolute and
+     * tight (scaled problem: unit rows, largest Hessian entry 1): a row with z < -1e-11 changes sides, and ends inactive
+     * with a violation below es if it was active with a zero multiplier. */
+    const double ez = 1e-11, es = 1e-9 * (1 + winf);
+    (void)zinf;
     for (int round = 0; round < POLISH_ROUNDS; round++) {
         if (factor(p, k, fix) != 0) { return 0; }
         memcpy(cw, cw0, sizeof(double) * p->M); /* the proximal centre starts at the interior-point iterate */

@@ -173,6 +173,25 @@ def test_trajectories_against_dense_active_set_solve():
     assert worst_raw < 1e-3          # (what the polish is for: measured 4e-5 on this set)
 
 
+def test_product_configuration_against_the_tight_one():
+    # The product polishes from an iterate that is only good to 1e-4; the result must still be THE vertex solution.
+    # Random prefixes with one initial state per node; this set holds nodes on which a clipped multiplier of -5e-8
+    # (sign tolerance of the first polish: 1e-9 relative) was worth 1.5e-4 in the trajectory.
+    from helpers import random_prefix_frontier
+    rng = np.random.default_rng(5)
+    fix = random_prefix_frontier(20, 4, 1024, p_one=0.05)
+    x0 = rng.uniform(-1, 1, (1024, 4)) * np.array([.3, .1, .6, .4])
+    a = make_controller('cart_pole_with_walls', backend='oracle', threads=8).qp.solve_batch(x0, fix)
+    b = make_controller('cart_pole_with_walls', backend='oracle', threads=8, tol=1e-10, polish_tol=1e-8).qp.solve_batch(x0, fix)
+    assert np.array_equal(a['status'], b['status'])
+    fin = a['status'] == 0
+    assert fin.sum() > 150 and np.all(a['polished'][fin] > 0) and np.all(b['polished'][fin] > 0)
+    xa, xb = a['primal'][fin][:, :84], b['primal'][fin][:, :84]
+    dev = np.max(np.abs(xa - xb), axis=1) / np.maximum(1e-2, np.max(np.abs(xb), axis=1))
+    assert dev.max() < 1e-6, dev.max()
+    np.testing.assert_allclose(a['obj'][fin], b['obj'][fin], rtol=1e-9, atol=1e-13)
+
+
 def test_results_do_not_depend_on_batch_or_threads():
     ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle')
     g = load_fixture('qp_golden')

@@ -1889,7 +1889,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     // Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides,
                     // but only those within a factor two of the worst violation / the most negative multiplier (a
                     // missing active row drags others across their bounds; the next round shows which are real).
-                    const double ez = 1e-9 * (1 + zinf / tau), es = 1e-9 * (1 + winf / tau);
+                    // (the sign test is absolute and tight: a clipped negative multiplier costs |z| / curvature of the
+                    // stage cost in the trajectory, a violated inactive row only its violation)
+                    const double ez = 1e-11, es = 1e-9 * (1 + winf / tau);
                     double vmax = 0, zmin = 0;
                     ROWS_BEGIN(k, rw)
                         const double d = R.D(k, rw.e);
