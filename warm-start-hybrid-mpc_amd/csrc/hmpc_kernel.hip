@@ -494,7 +494,7 @@ template <class D> struct RowMapL {
 
 template <class D, int KF, int KB, int KT> struct RowMapS {
     static constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
-    static constexpr int kSlots = KF + KB + KT;
+    static constexpr int kSlots = KF + KB + KT, kSlotsFB = KF + KB;
     static constexpr int SB = D::kNT / (2 * NUB); // stages per slot of bound rows
     static_assert(D::kNT % (2 * NUB) == 0, "bound rows must tile the workgroup");
     struct Ref { int e, v, row; };
@@ -580,6 +580,20 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
     }
     DEV bool active(const DevProb &, const Lds &, int k, const Ref &) const { return (act >> k) & 1u; }
     DEV double h(const DevProb &p, const Lds &, int k, const Ref &rw) const { return k < KF ? hF : k < KF + KB ? hB : p.ht[rw.row]; }
+    // The same product with the stage offset clamped to zero where the lane has no row in the slot: every lane loads from a
+    // valid address, so a phase can run the loads of ALL slots before its first store (straight-line code: a branch per
+    // slot exposes one LDS round trip per slot).  [F G] and bound slots only.
+    DEV double dot_all(int k, bool ok, const Ref &rw, const ldsd *vec) const
+    {
+        const ldsd *v = vec + (ok ? rw.v : 0);
+        if (k < KF) {
+            double a = cx[0] * v[0];
+#pragma unroll
+            for (int i = 1; i < NX; i++) a += cx[i] * v[i];
+            return (a + cu[0] * v[uo[0]]) + cu[1] * v[uo[1]];
+        }
+        return sgB * v[0];
+    }
     DEV double dot(const DevProb &p, const Lds &, int k, const Ref &rw, const ldsd *vec) const
     {
         const ldsd *v = vec + rw.v;
@@ -1502,13 +1516,41 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
         for (int l = 0; l < NX; l++) a += S.Pr[t * NXS + sym(i, l)] * dw[t * NZ + l];
         dlam[o] = -a;
     }
-    {
-        const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+    if constexpr (!D::kDpp) { // (15 slots per lane: the batched form below spills)
+        const int nslot = RS;
         ROWS_BEGIN(k, rw)
             const double d = R.D(k, rw.e);
             if (d != 0.0) // inactive rows keep e = 0
                 S.e[rw.e] = d * rm.dot(p, S, k, rw, dw) - S.e[rw.e];
         ROWS_END
+    } else {
+        // dz = D (C dw) - e on the [F G] and bound slots: all loads, then all stores (inactive rows keep e = 0)
+        constexpr int KS = RM::kSlotsFB;
+        double val[KS];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            typename RM::Ref rw;
+            const bool ok = rm.at(p, k, lane, rw);
+            const double d = ok ? R.D(k, rw.e) : 0.0;
+            val[k] = d * rm.dot_all(k, ok, rw, dw) - S.e[ok ? rw.e : 0];
+            if (d == 0.0) val[k] = __longlong_as_double(0x7ff8000000000000LL); // marks "no store"
+        }
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            typename RM::Ref rw;
+            (void)rm.at(p, k, lane, rw);
+            if (val[k] == val[k]) S.e[rw.e] = val[k];
+        }
+        if (S.term_on) { // terminal-set rows (dense, global memory): only in the second solve of a node
+#pragma unroll
+            for (int k = KS; k < RS; k++) {
+                typename RM::Ref rw;
+                if (rm.at(p, k, lane, rw)) {
+                    const double d = R.D(k, rw.e);
+                    if (d != 0.0) S.e[rw.e] = d * rm.dot(p, S, k, rw, dw) - S.e[rw.e];
+                }
+            }
+        }
     }
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
