@@ -351,12 +351,13 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         }
         h->allocs.push_back(p.fac_ws);
     }
-    if (hipMalloc((void **)&p.work_counter, sizeof(int)) != hipSuccess) {
+    if (hipMalloc((void **)&p.work_counter, 2 * sizeof(int)) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot allocate the work counter");
     }
     h->allocs.push_back(p.work_counter);
-    (void)hipMemset(p.work_counter, 0, sizeof(int));
+    (void)hipMemset(p.work_counter, 0, 2 * sizeof(int));
+    p.check_flag = (unsigned *)(p.work_counter + 1);
     if (hipMalloc((void **)&h->rows_ws, (size_t)h->max_grid * 4 * p.Mpad * sizeof(double)) != hipSuccess) {
         hmpc_destroy(h);
         return fail(HMPC_EDEVICE, "cannot allocate the row workspace");
@@ -626,6 +627,18 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
         if (out->dual) HIPCHK(hipMemcpyAsync(out->dual, ds + L.dual, dbytes, hipMemcpyDeviceToHost, nullptr));
     }
     HIPCHK(hipStreamSynchronize(nullptr));
+#ifdef HMPC_CHECK
+    {
+        unsigned flag = 0;
+        HIPCHK(hipMemcpy(&flag, h->dp.check_flag, sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) {
+            char msg[128];
+            snprintf(msg, sizeof msg, "HMPC_CHECK: in-kernel checks failed, flag bits 0x%x", flag);
+            (void)hipMemset(h->dp.check_flag, 0, sizeof flag);
+            return fail(HMPC_EDEVICE, msg);
+        }
+    }
+#endif
     if (out->obj) std::memcpy(out->obj, hs + L.obj, (size_t)B * sizeof(double));
     if (out->dual_obj) std::memcpy(out->dual_obj, hs + L.dobj, (size_t)B * sizeof(double));
     if (out->status) std::memcpy(out->status, hs + L.status, (size_t)B * sizeof(int32_t));

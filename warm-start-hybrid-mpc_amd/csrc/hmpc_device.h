@@ -35,6 +35,7 @@ struct DevProb {
     const double *F_raw, *G_raw, *h_raw, *hT_raw; // unscaled [F G | h] and h_Tm1 (warm-start shift, hmpc_shift.hip)
     const double *shift_Mmu, *shift_Mrho, *shift_V; // maps of the shift (hmpc_set_shift_maps), null until set
     int *work_counter;                         // nodes handed out beyond the first gridDim.x (zeroed before each launch)
+    unsigned *check_flag;                      // diagnostic build (HMPC_CHECK): bits raised by failed in-kernel checks; follows work_counter
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
     int dense_c_lds;                           // generic kernel: the dense stage rows are staged in LDS (they fit beside the rest)

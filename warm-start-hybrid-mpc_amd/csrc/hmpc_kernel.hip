@@ -300,10 +300,20 @@ struct Rows<0> {
 // The same for the thread index at the entry of a phase: addresses derived from it are recomputed per
 // phase (a few integer operations) instead of being kept in registers across the whole iteration.
 #define LANE_OPAQUE(lane) asm volatile("" : "+v"(lane))
+// Diagnostic build only (-DHMPC_CHECK, `make check`): every row handle and every gathered index is bounds-checked, the
+// per-node LDS vectors and the row slots are poisoned with NaNs at node start (a read of something never written shows up
+// as a NaN record), violations raise bits in a flag word the host reads after each launch.  Nothing of this is compiled
+// into the shipped kernel.
+#ifdef HMPC_CHECK
+#define HMPC_CHK(cond, bit) do { if (!(cond)) atomicOr(p.check_flag, 1u << (bit)); } while (0)
+#else
+#define HMPC_CHK(cond, bit) do { } while (0)
+#endif
 #define ROWS_BEGIN(k, rw)                                  \
     _Pragma("unroll") for (int k = 0; k < nslot; k++) {   \
         typename RM::Ref rw;                               \
-        if (rm.at(p, k, lane, rw)) {
+        if (rm.at(p, k, lane, rw)) {                       \
+            HMPC_CHK(rw.e >= 0 && rw.e < p.M, 0);
 #define ROWS_END }}
 
 // Row r -> (stage t, local row lr).  Rows [0, T*mreg) are the stage rows, mreg per stage; the
@@ -416,7 +426,7 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
             for (int q = 0; q < H; q++) cc[q] = cv[hb + q];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int q = 0; q < H; q++) ee[q] = eb[idx[q]];
+            for (int q = 0; q < H; q++) { HMPC_CHK(idx[q] >= 0 && idx[q] < p.mreg && j >= 0 && j < D::nz(p) && t >= 0 && t < p.T, 1); ee[q] = eb[idx[q]]; }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < H; q++) {
@@ -597,6 +607,7 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
     DEV double dot(const DevProb &p, const Lds &, int k, const Ref &rw, const ldsd *vec) const
     {
         const ldsd *v = vec + rw.v;
+        HMPC_CHK(rw.v >= 0 && (k >= KF && k < KF + KB ? rw.v < p.T * NZ : rw.v + NZ <= p.T * NZ) && uo[0] < NZ && uo[1] < NZ, 3);
         if (k < KF) {
             double a = cx[0] * v[0];
 #pragma unroll
@@ -948,7 +959,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < GH; q++) dv[q] = Dt[idx[q]];
+                    for (int q = 0; q < GH; q++) { HMPC_CHK(idx[q] >= 0 && idx[q] < p.mreg, 2); dv[q] = Dt[idx[q]]; }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < GH; q++) {
@@ -2391,6 +2402,20 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
             for (int bq = 0; bq < nub; bq++) all = all && S.fix[(st < T ? st : 0) * nub + bq] >= 0;
             S.fullfix = __ballot(all);
         }
+#ifdef HMPC_CHECK
+        {
+            const double poison = __longlong_as_double(0x7ff8dead0000beefLL);
+            // everything per node between the iterate and the staged constants (S.w .. S.mv); the node's inputs and the
+            // staged problem data are not touched
+            for (ldsd *q = S.w + lane; q < S.red; q += D::kNT) *q = poison;
+            const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
+#pragma unroll
+            for (int k = 0; k < nslot; k++) {
+                if constexpr (RS > 0) { R.s_[k] = poison; R.zd_[k] = poison; R.dz_[k] = poison; R.prod_[k] = poison; }
+            }
+            __syncthreads();
+        }
+#endif
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
         bool polished = false;
         double tau = 1.0;
@@ -2419,6 +2444,14 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
         __syncthreads();
         write_record<D>(p, S, lane, status, tau, qp, out);
+#ifdef HMPC_CHECK
+        if (status == HMPC_OPTIMAL) { // an optimal record holds no NaN
+            for (int o = lane; o < n; o += D::kNT) HMPC_CHK(S.w[o] == S.w[o], 4);
+            for (int o = lane; o < (T + 1) * nx; o += D::kNT) HMPC_CHK(S.lam[o] == S.lam[o], 5);
+            for (int o = lane; o < M; o += D::kNT) HMPC_CHK(S.e[o] == S.e[o], 6);
+        }
+        HMPC_CHK(status >= HMPC_OPTIMAL && status <= HMPC_NUMERICAL && tau > 0.0, 7);
+#endif
         if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0);
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
