@@ -45,6 +45,7 @@ extern "C" {
 #define HMPC_INFEASIBLE 1
 #define HMPC_MAXITER 2   /* not converged: the caller must not use the record */
 #define HMPC_NUMERICAL 3 /* numerical breakdown: idem */
+#define HMPC_UNBOUNDED 4 /* hmpc_lp_solve_batch only: the cost grows without bound on the set */
 
 #define HMPC_ITERS_POLISHED 0x10000 /* flag in hmpc_result.iters */
 
@@ -200,6 +201,27 @@ int hmpc_comm_unique_id(void *id128 /* 128 bytes out */);
 int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out);
 int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub /* in/out */, int32_t *open /* in/out */);
 int hmpc_comm_destroy(hmpc_comm *c);
+
+/* ---- batched dense LPs of the offline terminal ingredients ----
+ *
+ *     maximise c_k'x   subject to   A x <= b_k (+ 1 on row relax[k]),   x in R^n free,   k = 0 .. B-1
+ *
+ * One launch replaces one sweep of the reference's one-Gurobi-LP-at-a-time loops:
+ *   warm_start_hmpc/mcais.py:103-118       A = D_inf, c_k = (D A^t)_k, b = e_inf shared          (one sweep per horizon t)
+ *   warm_start_hmpc/mcais.py:169-182       A = E, c_k = E_k, b = f shared, relax[k] = k         (redundant facets)
+ *   warm_start_hmpc/controller.py:205-226  A = [F G], c_k = row k of [F_Tm1 G_Tm1], b = h shared; column k of the
+ *                                          multiplier map M is z[k] (the reference states the dual LP
+ *                                          min h'mu s.t. [F G]'mu = c_k, mu >= 0; HMPC_UNBOUNDED here is its "infeasible")
+ * Host arrays, row-major: A[m][n]; c[B][n] with c_stride = n, or one c[n] with c_stride = 0; b likewise with b_stride =
+ * m or 0; relax[B] or NULL (entries -1: none).  device < 0: the current device.  tol <= 0, max_iter <= 0: defaults
+ * (1e-9, 100).  Out: obj[B] = c_k'x (NaN unless optimal), x[B][n], z[B][m] >= 0 or NULL (A'z = c_k at an optimum; a
+ * Farkas ray A'z = 0, b'z < 0 when the set is empty), status[B] in {HMPC_OPTIMAL, HMPC_INFEASIBLE (empty set),
+ * HMPC_UNBOUNDED, HMPC_MAXITER, HMPC_NUMERICAL}, iters[B].  Limits: n <= 64; the row vectors of one LP must fit one
+ * CU's LDS (m <~ 1800).  Values of an optimum are exact to rounding (the interior-point iterate is moved to the
+ * vertex), so the reference's comparisons with 0 (mcais.py:128) and 1e-7 (mcais.py:181) see what a simplex code shows. */
+int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, const double *c, int32_t c_stride,
+                        const double *b, int32_t b_stride, const int32_t *relax, int32_t B, double tol, int32_t max_iter,
+                        double *obj, double *x, double *z, int32_t *status, int32_t *iters);
 
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);

@@ -42,6 +42,12 @@ def _d(a):
 class OracleBatchedQP(object):
     """CPU oracle behind the backend interface of the controller."""
 
+    @staticmethod
+    def lp_solve_batch(A, c, b, relax=None, **kw):
+        """The facet LPs of the offline ingredients on the LP oracle (oracle/dense_lp.c)."""
+        from oracle.oracle_lp import lp_solve_batch
+        return lp_solve_batch(A, c, b, relax=relax, **kw)
+
     def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, threads=1, lazy_terminal=True, refine=True, polish=True, polish_tol=1e-4):
         self.lib = _load()
         c = lambda M: np.ascontiguousarray(np.atleast_2d(M), dtype=np.float64)

@@ -33,6 +33,8 @@ for name in ('pympc', 'pympc.dynamics', 'pympc.dynamics.discretization_methods')
 sys.modules['pympc.dynamics.discretization_methods'].zero_order_hold = None
 
 from warm_start_hmpc_amd.terminal_set import solve_dare, mcais, update_mu  # noqa: E402
+sys.path.insert(0, os.path.dirname(HERE))
+from highs_lp import lp_solve_batch as HIGHS  # noqa: E402  (the fixtures come from an independent LP solver)
 
 
 def two_walls():
@@ -46,10 +48,10 @@ def two_walls():
     P, K = solve_dare(mld.A, Bu, Q.dot(Q), Ru.dot(Ru))
     Q_T = np.linalg.cholesky(P).T
     A_cl = mld.A + Bu.dot(K)
-    F_T, h_T = mcais(A_cl, mld.F + mld.G[:, :1].dot(K), mld.h, verbose=True)
+    F_T, h_T = mcais(A_cl, mld.F + mld.G[:, :1].dot(K), mld.h, verbose=True, lp=HIGHS)
     F_Tm1 = np.vstack((mld.F, F_T.dot(mld.A)))
     G_Tm1 = np.vstack((mld.G, F_T.dot(mld.B)))
-    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1)
+    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1, lp=HIGHS)
     np.savez(os.path.join(HERE, 'cart_pole_with_walls.npz'),
              A=np.array(mld.A, dtype=float), B=np.array(mld.B, dtype=float),
              F=np.array(mld.F, dtype=float), G=np.array(mld.G, dtype=float),
@@ -100,7 +102,7 @@ def one_wall():
     h_T = np.concatenate((x_max, x_max)) / 1.1
     F_Tm1 = np.vstack((mld.F, F_T.dot(mld.A)))
     G_Tm1 = np.vstack((mld.G, F_T.dot(mld.B)))
-    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1)
+    M = update_mu(mld.F, mld.G, mld.h, F_Tm1, G_Tm1, lp=HIGHS)
     np.savez(os.path.join(HERE, 'cart_pole_one_wall.npz'),
              A=np.array(mld.A, dtype=float), B=np.array(mld.B, dtype=float),
              F=np.array(mld.F, dtype=float), G=np.array(mld.G, dtype=float),

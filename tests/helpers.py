@@ -13,6 +13,15 @@ class _NoBackend(object):
     """Placeholder so that a controller can be built before its backend exists."""
 
 
+def lp_for(backend):
+    """Batched LP solver that goes with a backend: the HIP kernel for the product path, the LP oracle otherwise."""
+    if backend == 'hip':
+        from warm_start_hmpc_amd.qp_backend import lp_solve_batch
+    else:
+        from oracle.oracle_lp import lp_solve_batch
+    return lp_solve_batch
+
+
 def load_fixture(name):
     return np.load(os.path.join(GOLDEN, name + '.npz'))
 
@@ -23,7 +32,7 @@ def make_controller(name='cart_pole_with_walls', T=None, terminal=True, backend=
     mld = MLDSystem([d['A'], d['B']], [d['F'], d['G'], d['h']], int(d['nub']))
     T = int(d['T']) if T is None else T
     term = [d['F_T'], d['h_T']] if terminal else None
-    ctrl = HybridModelPredictiveController(mld, T, [d['Q'], d['R'], d['Q_T']], term, backend=_NoBackend())
+    ctrl = HybridModelPredictiveController(mld, T, [d['Q'], d['R'], d['Q_T']], term, backend=_NoBackend(), lp=lp_for(backend))
     if backend == 'oracle':
         from oracle.oracle_qp import OracleBatchedQP
         ctrl.qp = OracleBatchedQP(ctrl.problem_data(), **opts)

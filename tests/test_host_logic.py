@@ -5,7 +5,7 @@ from copy import copy
 import numpy as np
 import pytest
 
-from helpers import make_controller, load_fixture, _NoBackend, exercise_bounded_qp
+from helpers import make_controller, load_fixture, _NoBackend, exercise_bounded_qp, lp_for
 from warm_start_hmpc_amd.mld_system import MLDSystem
 from warm_start_hmpc_amd.controller import HybridModelPredictiveController, branch_in_time
 from warm_start_hmpc_amd.branch_and_bound import Node, branch_and_bound, best_first, depth_first, breadth_first
@@ -37,9 +37,9 @@ def test_init_rejects_wrong_sizes():
 def test_update_matrices():
     # reference: test_controller.py:40-59
     d, mld, objective, terminal = _one_wall()
-    ctrl = HybridModelPredictiveController(mld, 40, objective, terminal, backend=_NoBackend())
+    ctrl = HybridModelPredictiveController(mld, 40, objective, terminal, backend=_NoBackend(), lp=lp_for('oracle'))
     np.testing.assert_array_equal(ctrl._update['rho'], 1.1 * np.eye(mld.nx))
-    free = HybridModelPredictiveController(mld, 40, objective, [np.empty((0, mld.nx)), np.empty(0)], backend=_NoBackend())
+    free = HybridModelPredictiveController(mld, 40, objective, [np.empty((0, mld.nx)), np.empty(0)], backend=_NoBackend(), lp=lp_for('oracle'))
     np.testing.assert_allclose(free._update['mu'], np.eye(mld.F.shape[0]), atol=1e-12)
     M = ctrl._update['mu']
     assert np.min(M) >= 0

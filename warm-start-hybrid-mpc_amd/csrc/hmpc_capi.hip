@@ -675,3 +675,4 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
 
 #include "hmpc_fleet.hip" // closed loops in lockstep (same translation unit: uses the launchers above)
 #include "hmpc_comm.hip"  // incumbent all-reduce over RCCL
+#include "hmpc_lp.hip"    // batched dense LPs of the offline terminal ingredients

@@ -43,9 +43,26 @@ def branch_in_time(identifier, nub):
     return [{(t, i): 0.}, {(t, i): 1.}]
 
 
+class _ShiftMaps(dict):
+    """``{'mu': M, 'rho': ...}`` of controller.py:94-97; ``'mu'`` is computed by the controller's LP solver (its
+    ``lp=`` argument, else its backend's ``lp_solve_batch``, else the HIP LP kernel) the first time it is read."""
+
+    def __init__(self, controller):
+        dict.__init__(self)
+        self._controller = controller
+
+    def __missing__(self, key):
+        if key != 'mu':
+            raise KeyError(key)
+        c = self._controller
+        lp = c._lp or getattr(c.qp, 'lp_solve_batch', None)
+        self['mu'] = update_mu(c.mld.F, c.mld.G, c.mld.h, c.F_Tm1, c.G_Tm1, lp=lp)
+        return self['mu']
+
+
 class HybridModelPredictiveController(object):
 
-    def __init__(self, mld, T, objective, terminal_set, backend=None, solver_params=None):
+    def __init__(self, mld, T, objective, terminal_set, backend=None, solver_params=None, lp=None):
         '''
         Parameters
         ----------
@@ -58,6 +75,9 @@ class HybridModelPredictiveController(object):
             there is no CPU fallback in the product path).
         solver_params : dict, options of the batched QP solver
             (``tol``, ``max_iter``); replaces the reference's ``gurobi_params``.
+        lp : batched LP solver for the multiplier map of the warm start
+            (``terminal_set.update_mu``, controller.py:186-227); default: the
+            backend's ``lp_solve_batch`` if it has one, else the HIP LP kernel.
         '''
         self.mld = mld
         self.T = int(T)
@@ -76,17 +96,20 @@ class HybridModelPredictiveController(object):
         self.layout = RecordLayout(mld.nx, mld.nu, mld.nub, self.T, mld.h.size, self.h_Tm1.size,
                                    self.Q.shape[0], self.R.shape[0], self.Q_T.shape[0])
 
-        # warm start construction (controller.py:94-97)
-        self._update = {
-            'mu': update_mu(mld.F, mld.G, mld.h, self.F_Tm1, self.G_Tm1),
-            'rho': np.linalg.pinv(self.Q.T).dot(self.Q_T.T),
-        }
+        # warm start construction (controller.py:94-97).  The multiplier map is one batched launch of the LP kernel
+        # (controller.py:186-227); it is computed here, as in the reference, whenever an LP solver is at hand, and on
+        # first use when the controller is built around a placeholder backend that is bound afterwards.
+        self._lp = lp
+        self._update = _ShiftMaps(self)
+        self._update['rho'] = np.linalg.pinv(self.Q.T).dot(self.Q_T.T)
 
         self.solver_params = dict(solver_params or {})
         if backend is None:
             from .qp_backend import HipBatchedQP  # fails loudly without the HIP library / a GPU
             backend = HipBatchedQP(self.problem_data(), **self.solver_params)
         self.qp = backend
+        if lp is not None or hasattr(backend, 'lp_solve_batch'):
+            self._update['mu']
 
     def problem_data(self):
         """Node-independent data of the QP, as the C ABI takes it (include/hmpc.h)."""

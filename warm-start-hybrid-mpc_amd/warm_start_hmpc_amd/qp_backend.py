@@ -103,6 +103,10 @@ def load_library():
         lib.hmpc_allreduce_incumbent.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
         lib.hmpc_comm_destroy.restype = ctypes.c_int
         lib.hmpc_comm_destroy.argtypes = [ctypes.c_void_p]
+        lib.hmpc_lp_solve_batch.restype = ctypes.c_int
+        lib.hmpc_lp_solve_batch.argtypes = ([ctypes.c_int32] * 3 + [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                             ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_double, ctypes.c_int32]
+                                            + [ctypes.c_void_p] * 5)
         _lib = lib
     return _lib
 
@@ -111,7 +115,42 @@ EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_la
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_comm_destroy')
+                    'hmpc_fleet_stats', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_comm_destroy',
+                    'hmpc_lp_solve_batch')
+
+
+def lp_solve_batch(A, c, b, relax=None, tol=1e-9, max_iter=100, device=-1):
+    """The facet LPs of the offline terminal ingredients, one launch per sweep (``hmpc_lp_solve_batch``).
+
+    maximise ``c_k'x`` s.t. ``A x <= b_k`` (+1 on row ``relax[k]``); ``c``: [n] or [B, n], ``b``: [m] or [B, m].
+    Returns ``dict(obj[B], x[B, n], z[B, m], status[B], iters[B])``; status 0 optimal, 1 empty set, 4 unbounded.
+    Replaces the Gurobi LP loops of ``mcais.py:103-118, 169-182`` and ``controller.py:205-226``.  Raises without the
+    HIP library or a GPU: there is no CPU path.
+    """
+    lib = load_library()
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    if A.ndim != 2:
+        raise ValueError('lp_solve_batch: A must be a matrix')
+    m, n = A.shape
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    B = max(c.shape[0] if c.ndim == 2 else 1, b.shape[0] if b.ndim == 2 else 1, 0 if relax is None else len(relax))
+    if ((c.ndim == 2 and c.shape != (B, n)) or (c.ndim == 1 and c.size != n) or c.ndim > 2 or
+            (b.ndim == 2 and b.shape != (B, m)) or (b.ndim == 1 and b.size != m) or b.ndim > 2):
+        raise ValueError('lp_solve_batch: inconsistent sizes')
+    rl = None
+    if relax is not None:
+        rl = np.ascontiguousarray(relax, dtype=np.int32)
+        if rl.shape != (B,):
+            raise ValueError('lp_solve_batch: relax must have one entry per LP')
+    obj = np.empty(B); x = np.empty((B, n)); z = np.empty((B, m))
+    status = np.empty(B, dtype=np.int32); iters = np.empty(B, dtype=np.int32)
+    rc = lib.hmpc_lp_solve_batch(device, n, m, A.ctypes.data, c.ctypes.data, n if c.ndim == 2 else 0, b.ctypes.data,
+                                 m if b.ndim == 2 else 0, rl.ctypes.data if rl is not None else None, B, tol, max_iter,
+                                 obj.ctypes.data, x.ctypes.data, z.ctypes.data, status.ctypes.data, iters.ctypes.data)
+    if rc != 0:
+        raise RuntimeError('hmpc_lp_solve_batch failed (%d): %s' % (rc, lib.hmpc_last_error().decode()))
+    return dict(obj=obj, x=x, z=z, status=status, iters=iters)
 
 
 class HipBatchedQP(object):
@@ -125,6 +164,7 @@ class HipBatchedQP(object):
     def __init__(self, problem, tol=1e-8, tol_inf=1e-6, max_iter=100, lazy_terminal=True, refine=True, device=-1,
                  polish=True, polish_tol=1e-4):
         self.lib = load_library()
+        self.device = int(device)
         keep = {}
         for k in ('A', 'B', 'F', 'G', 'F_Tm1', 'G_Tm1', 'Q', 'R', 'Q_T'):
             keep[k] = np.ascontiguousarray(np.atleast_2d(problem[k]), dtype=np.float64)
@@ -165,6 +205,10 @@ class HipBatchedQP(object):
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError('hmpc call failed (%d): %s' % (rc, self.lib.hmpc_last_error().decode()))
+
+    def lp_solve_batch(self, A, c, b, relax=None, **kw):
+        """The facet LPs of the offline ingredients on this backend's device (see module-level ``lp_solve_batch``)."""
+        return lp_solve_batch(A, c, b, relax=relax, device=self.device, **kw)
 
     def solve_batch(self, x0, fix, want_primal=True, want_dual=True):
         """Host arrays in, host arrays out (copies included in ``time``).
