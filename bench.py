@@ -207,6 +207,47 @@ def other_configs(dev):
     return out
 
 
+def offline_lps():
+    """the terminal ingredients of the cart-pole controller (mcais.py:44-184, controller.py:186-227)
+    on the batched LP kernel -- one launch per sweep of the reference's one-LP-at-a-time loops.  Wall time of the whole
+    construction (host copies and Python included); cpu_baseline: the same calls on the LP oracle, one host core."""
+    from helpers import load_fixture
+    from warm_start_hmpc_amd import terminal_set as ts
+    from warm_start_hmpc_amd.qp_backend import lp_solve_batch
+    d = load_fixture('cart_pole_with_walls')
+    A_cl, D = d['A'] + d['B'][:, :1].dot(d['K']), d['F'] + d['G'][:, :1].dot(d['K'])
+    count = {'lps': 0, 'launches': 0}
+
+    def counted(lp):
+        def call(A, c, b, relax=None):
+            r = lp(A, c, b, relax=relax)
+            count['lps'] += r['obj'].size
+            count['launches'] += 1
+            return r
+        return call
+
+    def build(lp):
+        F_T, h_T = ts.mcais(A_cl, D, d['h'], lp=lp)
+        M = ts.update_mu(d['F'], d['G'], d['h'], np.vstack((d['F'], F_T.dot(d['A']))), np.vstack((d['G'], F_T.dot(d['B']))), lp=lp)
+        return F_T, M
+
+    build(lp_solve_batch)                       # warm-up (module load)
+    t0 = time.perf_counter()
+    F_T, M = build(counted(lp_solve_batch))
+    gpu_s = time.perf_counter() - t0
+    out = {'lps': count['lps'], 'launches': count['launches'], 'facets': int(F_T.shape[0]), 'wall_ms': gpu_s * 1e3,
+           'lps_per_sec': count['lps'] / gpu_s, 'same_set_as_fixture': bool(F_T.shape == d['F_T'].shape and np.allclose(F_T, d['F_T'], atol=1e-12))}
+    try:
+        from oracle.oracle_lp import lp_solve_batch as cpu_lp     # cpu_baseline leg
+        t0 = time.perf_counter()
+        build(cpu_lp)
+        cpu_s = time.perf_counter() - t0
+        out['cpu_baseline'] = {'wall_ms': cpu_s * 1e3, 'lps_per_sec': count['lps'] / cpu_s, 'cores': 1, 'kind': 'port'}
+    except Exception as e:
+        out['cpu_baseline'] = {'error': repr(e)}
+    return out
+
+
 def mpc_steps_per_sec(ctrl, steps=10, sims=64):
     """Closed-loop MPC steps/s (warm-started B&B, sigma = 0.001), the second figure of BASELINE.json's
     metric: (a) one loop alone (latency bound: a handful of sequential B&B rounds per step) and (b) `sims`
@@ -445,7 +486,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.workload == 'cart_pole_n20':
             for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, x0_h)), ('other_configs', lambda: other_configs(dev)),
-                            ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl))):
+                            ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl)), ('offline_lps', offline_lps)):
                 try:
                     line[key] = fn()
                 except Exception as e:  # secondary figures never hide the main line

@@ -490,6 +490,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
         }
         /* the active rows must be met, and the proximal term (dropped from the multipliers) must have died out:
          * it is the stationarity residual of the result */
+        if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      polish round %d pinf %.3e pmove %.3e\n", round, pinf, pmove);
         if (!(pinf <= 1e-10 * (1 + winf)) || !(POLISH_DELTA * pmove <= 1e-12 * (1 + zinf))) return 0;
         /* Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides, but only those
          * within a factor two of the worst violation / the most negative multiplier (a missing active row drags
@@ -504,6 +505,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
                 else if (cw[q] - hh[r] > vmax) vmax = cw[q] - hh[r];
             }
         }
+        if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      polish round %d vmax %.3e zmin %.3e\n", round, vmax, zmin);
         if (vmax <= es && zmin >= -ez) {
             for (int q = 0; q < p->M; q++) if (k->D[q] == POLISH_RHO && zk[q] < 0) zk[q] = 0;
             return 1;
