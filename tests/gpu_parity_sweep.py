@@ -43,3 +43,33 @@ for rep in range(int(os.environ.get('DBG_REPS', 24))):
 print('TOTAL nodes %d, status mismatches %d, worst state-trajectory deviation %.2e (penalised input %.2e), nodes above 1e-5: %d, optimal nodes left unpolished by the kernel: %d'
       % (tot, bad_status, worst, worst_fc, nbig, unpolished))
 print('against the tight oracle: worst deviation %.2e, nodes above 1e-5: %d' % (worst_tight, nbig_tight))
+
+# ---- second family: shallow prefixes, wide initial states (feasible-heavy; the nodes whose active sets need the second
+# penalty level of the polish live here), every system; the kernel against the oracle and -- independent of both --
+# against the dense active-set solve of tests/dense_qp.py on the first 300 optimal nodes of each batch
+import dense_qp
+for name, T2, B, width, depth, p1 in (('cart_pole_one_wall', 40, 12000, .6, 30, .15), ('cart_pole_with_walls', 20, 6000, .5, 40, .3),
+                                     ('cart_pole_with_walls', 40, 3000, .5, 40, .3)):
+    h2 = make_controller(name, T=T2, backend='hip')
+    o2 = make_controller(name, T=T2, backend='oracle', threads=16)
+    nub = h2.mld.nub
+    r2 = np.random.RandomState(3)
+    fix = np.full((B, T2 * nub), -1, np.int8)
+    for k in range(B):
+        dep = r2.randint(0, depth)
+        fix[k, :dep] = r2.rand(dep) < p1
+    from helpers import load_fixture
+    x0 = (r2.rand(B, 4) - .5) * 2 * load_fixture(name)['x_max'] * width
+    a, b = h2.qp.solve_batch(x0, fix), o2.qp.solve_batch(x0, fix)
+    fin = (a['status'] == 0) & (b['status'] == 0)
+    xa, xb = a['primal'][fin][:, :(T2 + 1) * 4], b['primal'][fin][:, :(T2 + 1) * 4]
+    dev = np.max(np.abs(xa - xb), axis=1) / np.maximum(1e-2, np.max(np.abs(xb), axis=1))
+    dq = dense_qp.dense_qp(h2)
+    wd = 0.
+    for i in np.flatnonzero(fin & (a['polished'] > 0))[:300]:
+        w, _ = dense_qp.active_set_primal(h2, dq, x0[i], fix[i], a['dual'][i])
+        X = a['primal'][i][:(T2 + 1) * 4]
+        wd = max(wd, float(np.abs(X - w[:(T2 + 1) * 4]).max() / (1 + np.abs(X).max())))
+    print('%s N=%d shallow/wide: nodes %d, status mismatches %d, optimal %d, unpolished hip %d oracle %d, worst dev hip-oracle %.2e, hip-dense %.2e, iterations per optimal node %.2f'
+          % (name, T2, B, int((a['status'] != b['status']).sum()), int(fin.sum()), int((a['polished'][fin] == 0).sum()),
+             int((b['polished'][fin] == 0).sum()), float(dev.max()), wd, float((a['iters'][fin] & 0xFFFF).mean())), flush=True)

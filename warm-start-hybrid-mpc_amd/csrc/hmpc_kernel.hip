@@ -40,6 +40,7 @@
 // active-set polish (same constants as oracle/hsde_qp.c): penalty of the active rows, proximal weight of the
 // inactive rows (must stay above eps * rho), multiplier steps per active set, active sets per attempt
 #define HMPC_POLISH_RHO 1e5
+#define HMPC_POLISH_RHO2 1e7 // second level, for active sets whose multiplier steps do not settle at the first
 #define HMPC_POLISH_DELTA 1e-10
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
@@ -1674,6 +1675,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // active set, with factorisation; mode 2: a further multiplier step with the factorisation at hand): the
     // polish reuses the factorisation and the constant-direction solve below instead of owning copies of them.
     int mode = 0, round = 0, al = 0;
+    double rho = HMPC_POLISH_RHO; // penalty of the polish in progress
+    int level = 0;                // 0: first penalty level; 1: second; 2: back at the first for the last digits
     double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
     for (it = 0; it <= p.max_iter;) {
       if (mode == 0) {
@@ -1854,13 +1857,15 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 if (zr != 0.0) {
                     const bool active = zr > R.s(k, rw.e) || ((amask >> (k & 63)) & 1ull);
                     R.prod(k, rw.e) = zr; // kept for the way back
-                    if (active) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
+                    if (active) { d = rho; R.dz(k, rw.e) = zr / tau; }
                     else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
                     R.D(k, rw.e) = d;
                 }
                 S.e[rw.e] = d;
             ROWS_END
             mode = 1; round = 0; al = 0;
+            rho = HMPC_POLISH_RHO;
+            level = 0;
             attempts++;
         } else {
             ROWS_BEGIN(k, rw)
@@ -1899,7 +1904,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             ROWS_BEGIN(k, rw)
                 const double d = R.D(k, rw.e);
                 double v = d * rm.h(p, S, k, rw); // right-hand side of the constant direction
-                if (mode != 0) v = d == HMPC_POLISH_RHO ? v - R.dz(k, rw.e) : d * R.dz(k, rw.e);
+                if (mode != 0) v = d >= 1.0 ? v - R.dz(k, rw.e) : d * R.dz(k, rw.e);
                 S.e[rw.e] = v;
             ROWS_END
             if (mode == 2)
@@ -1916,7 +1921,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 double pinf = 0, pmove = 0;
                 ROWS_BEGIN(k, rw)
                     const double d = R.D(k, rw.e);
-                    if (d == HMPC_POLISH_RHO) { // multiplier step
+                    if (d >= 1.0) { // multiplier step
                         const double zn = S.e[rw.e];
                         pinf = fmax(pinf, fabs(zn - R.dz(k, rw.e)));
                         R.dz(k, rw.e) = zn;
@@ -1930,13 +1935,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     double v[2] = {pinf, pmove};
                     const int op[2] = {1, 1};
                     block_reduce<D, 2>(v, op, S.red, lane);
-                    pinf = v[0] / HMPC_POLISH_RHO; pmove = v[1];
+                    pinf = v[0] / rho; pmove = v[1];
                 }
                 if (!((al >= 1 && pinf <= 1e-12 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-13) || al == HMPC_POLISH_ITERS - 1)) {
                     al++;
                     mode = 2;
                     outcome = 2;
-                } else if (pinf <= 1e-10 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-12 * (1 + zinf / tau)) {
+                } else if (pinf <= (level == 0 ? 1e-12 : 1e-10) * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-12 * (1 + zinf / tau)) {
                     // (otherwise give up: the active rows are not met, or the proximal term -- dropped from the
                     // multipliers, hence the stationarity residual of the result -- has not died out)
                     // Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides,
@@ -1948,7 +1953,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     double vmax = 0, zmin = 0;
                     ROWS_BEGIN(k, rw)
                         const double d = R.D(k, rw.e);
-                        if (d == HMPC_POLISH_RHO) zmin = fmin(zmin, R.dz(k, rw.e));
+                        if (d >= 1.0) zmin = fmin(zmin, R.dz(k, rw.e));
                         else if (d != 0.0) vmax = fmax(vmax, R.dz(k, rw.e) - rm.h(p, S, k, rw));
                     ROWS_END
                     {
@@ -1958,13 +1963,32 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         vmax = v[0]; zmin = v[1];
                     }
                     if (vmax <= es && zmin >= -ez) {
-                        outcome = 1;
+                        if (level == 1 && round + 1 < HMPC_POLISH_ROUNDS) {
+                            // verified at the second level: the same active set once more at the first, from these
+                            // multipliers (what is left to settle are the components that matter, of the size of the
+                            // second level's rounding; the slow ones are in place)
+                            level = 2;
+                            rho = HMPC_POLISH_RHO;
+                            round++;
+                            ROWS_BEGIN(k, rw)
+                                double d = R.D(k, rw.e);
+                                if (d >= 1.0) { d = rho; R.D(k, rw.e) = d; }
+                                else if (d != 0.0) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
+                                S.e[rw.e] = d;
+                            ROWS_END
+                            __syncthreads();
+                            al = 0;
+                            mode = 1;
+                            outcome = 2;
+                        } else {
+                            outcome = 1;
+                        }
                     } else if (++round < HMPC_POLISH_ROUNDS) {
                         ROWS_BEGIN(k, rw)
                             double d = R.D(k, rw.e);
                             if (d != 0.0) {
-                                if (d != HMPC_POLISH_RHO) {
-                                    if (vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = 0.0; }
+                                if (d < 1.0) {
+                                    if (vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = rho; R.dz(k, rw.e) = 0.0; }
                                 } else if (zmin < -ez && R.dz(k, rw.e) < 0.5 * zmin) {
                                     d = HMPC_POLISH_DELTA;
                                 }
@@ -1979,6 +2003,24 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         mode = 1;
                         outcome = 2;
                     }
+                } else if (level == 0 && pinf == pinf && ++round < HMPC_POLISH_ROUNDS) {
+                    // The multiplier steps contract by 1 / (1 + rho lambda), lambda the eigenvalues of C_A Phi^-1 C_A':
+                    // active rows that nearly depend on each other do not settle at the first level.  They do at the
+                    // second -- not the first choice: eps rho is no longer below the proximal weight there (1e-9 in the
+                    // multipliers, ~1e-6 in the trajectory) --, used once per attempt where the first fails; its result
+                    // goes through the first level once more (level 2).  Same as oracle/hsde_qp.c polish().
+                    level = 1;
+                    rho = HMPC_POLISH_RHO2;
+                    ROWS_BEGIN(k, rw)
+                        double d = R.D(k, rw.e);
+                        if (d >= 1.0) { d = rho; R.D(k, rw.e) = d; }
+                        else if (d != 0.0) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
+                        S.e[rw.e] = d;
+                    ROWS_END
+                    __syncthreads();
+                    al = 0;
+                    mode = 1;
+                    outcome = 2;
                 }
             }
             if (outcome == 2) continue;
@@ -1988,7 +2030,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] = S.nuf1[o];
                 ROWS_BEGIN(k, rw)
                     const double d = R.D(k, rw.e);
-                    if (d != 0.0) R.z(k, rw.e) = d == HMPC_POLISH_RHO ? fmax(R.dz(k, rw.e), 0.0) : 0.0;
+                    if (d != 0.0) R.z(k, rw.e) = d >= 1.0 ? fmax(R.dz(k, rw.e), 0.0) : 0.0;
                 ROWS_END
                 tau = 1.0;
                 status = HMPC_OPTIMAL;
