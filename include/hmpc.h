@@ -195,7 +195,10 @@ int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
  * largest count on any rank (zero exactly when all ranks are done: they stop in the same round).  One all-reduce
  * (MIN) of two float64.  Setup as for any RCCL communicator: rank 0 calls hmpc_comm_unique_id and hands the
  * 128 bytes to the other ranks (the caller's transport), then every rank calls hmpc_comm_create.  RCCL is
- * loaded at run time; a process that never creates a communicator does not need it. */
+ * loaded at run time; a process that never creates a communicator does not need it.
+ * A rank whose own search failed still owes the others the round they are waiting in: it calls once more with
+ * *ub = -INFINITY, and every rank that receives -INFINITY stops with an error of its own (the convention of
+ * warm_start_hmpc_amd/distributed.py: IncumbentExchange.abort / PeerFailure). */
 typedef struct hmpc_comm hmpc_comm;
 int hmpc_comm_unique_id(void *id128 /* 128 bytes out */);
 int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out);

@@ -72,6 +72,53 @@ def test_two_ranks_agree_with_single_process():
         assert np.array_equal(np.array(assign), np.array(single[0].variables['ub']))
 
 
+def _failing_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from helpers import make_controller
+    from warm_start_hmpc_amd.distributed import feedforward_sharded, PeerFailure
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle')
+    x0 = np.array([0., 0., .5, 0.])
+    sol, leaves, _, _ = ctrl.feedforward(x0, printing_period=None)
+    cover = ctrl.construct_warm_start(leaves, x0, sol.variables['uc'][0], sol.variables['ub'][0], np.zeros(4))[0]
+    if rank == 1:                                  # this rank's solver breaks down in its third round
+        good, calls = ctrl.qp.solve_batch, [0]
+
+        def solve_batch(x, fix, **kw):
+            calls[0] += 1
+            res = good(x, fix, **kw)
+            if calls[0] == 3:
+                res['status'][:] = 3               # NUMERICAL: the controller raises
+            return res
+        ctrl.qp.solve_batch = solve_batch
+    try:
+        feedforward_sharded(ctrl, sol.variables['x'][1], cover, frontier_width=2)
+        q.put((rank, 'no error'))
+    except PeerFailure:
+        q.put((rank, 'peer'))
+    except RuntimeError:
+        q.put((rank, 'own'))
+    dist.barrier()                                 # both ranks are out of the search: nobody hangs
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_does_not_leave_the_other_in_a_collective():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got == {0: 'peer', 1: 'own'}
+
+
 def _mc_worker(rank, world, port, out):
     for p in (ROOT, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'), os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)

@@ -9,6 +9,12 @@ float64 (ub, -open): the first entry is the global upper bound, minus the second
 number of open candidates on any rank, zero exactly when every rank is done -- so that every
 rank prunes against the global best and all ranks stop together.  The same exchange is offered
 to non-Python callers of the library as ``hmpc_allreduce_incumbent`` (include/hmpc.h, RCCL).
+
+A rank whose search fails (a node that ends MAXITER / NUMERICAL raises, as in the reference a
+Gurobi status other than optimal / infeasible does, ``bounded_qp.py:216-228``) still owes the
+other ranks this round's all-reduce: it contributes an upper bound of -inf before re-raising,
+which every other rank reads as "a peer failed" and raises ``PeerFailure`` -- no rank is left
+waiting in a collective.
 """
 import numpy as np
 
@@ -17,6 +23,10 @@ def shard_indices(count, rank, world):
     """Indices of the nodes of a ``count``-node frontier owned by ``rank`` (round-robin: node k
     goes to rank k % world, which balances random-depth nodes)."""
     return np.arange(rank, count, world)
+
+
+class PeerFailure(RuntimeError):
+    """Another rank's search raised; this rank's result would be incomplete."""
 
 
 class IncumbentExchange(object):
@@ -35,7 +45,14 @@ class IncumbentExchange(object):
         dist.all_reduce(pair, op=dist.ReduceOp.MIN, group=self.group)
         self.rounds += 1
         ub_all, open_max = pair.tolist()          # (the search only asks whether ANY rank still has candidates)
+        if ub_all == -np.inf:
+            raise PeerFailure('the branch and bound of another rank failed')
         return float(ub_all), int(round(-open_max))
+
+    def abort(self):
+        """This rank's contribution to the round the others are waiting in, after its own search failed."""
+        pair = self.torch.tensor([-np.inf, 0.], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(pair, op=self.dist.ReduceOp.MIN, group=self.group)
 
 
 def solve_frontier_sharded(ctrl, fix, x0, group=None, device=None):
@@ -72,7 +89,13 @@ def feedforward_sharded(ctrl, x0, cover, group=None, device=None, **kwargs):
     if not mine:
         from .branch_and_bound import Node
         mine = [Node({}, lb=np.inf)]  # nothing to do, but keep taking part in the rounds
-    sol, leaves, solves, _ = ctrl.feedforward(x0, warm_start=mine, incumbent_exchange=exchange, **kwargs)
+    try:
+        sol, leaves, solves, _ = ctrl.feedforward(x0, warm_start=mine, incumbent_exchange=exchange, **kwargs)
+    except PeerFailure:
+        raise
+    except Exception:
+        exchange.abort()                      # the round the other ranks are waiting in
+        raise
     local = np.inf if sol is None else sol.objective
     # the owner of the global incumbent (lowest rank on ties) publishes its assignment
     gathered = [None] * world
