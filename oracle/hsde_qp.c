@@ -424,6 +424,9 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
  * the interior-point iteration simply goes on (nothing of its state is touched).
  * Outputs (tau = 1 units): k->w1, lam1, nuf1 and the row multipliers in k->dza.
  */
+#ifndef REFINE_FROM_IT
+#define REFINE_FROM_IT 12
+#endif
 #define POLISH_RHO 1e5      /* penalty of the active rows (scaled problem: unit rows, largest Hessian entry 1) */
 #define POLISH_RHO2 1e7     /* second level, for active sets whose multiplier steps do not settle at the first        */
 #define POLISH_DELTA 1e-10 /* proximal weight of the inactive rows; must stay above eps * rho            */
@@ -727,7 +730,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
              * K d = rhs2 + dtau rhs1: one step once mu < 1e-3, two once mu < 1e-7 (one step squares the
              * relative error of a solve, and the stage cost's small curvature needs the dual residual
              * well below the stopping tolerance for the trajectory to be accurate to 1e-5) */
-            const int nref = (pass == 1 && refine) ? (mu < REFINE_MU2 ? 2 : mu < REFINE_MU ? 1 : 0) : 0;
+            const int nref = (pass == 1 && refine && (it >= REFINE_FROM_IT || npol > 0 || !do_polish)) ? (mu < REFINE_MU2 ? 2 : mu < REFINE_MU ? 1 : 0) : 0;
             for (int rf = 0; rf < nref; rf++) {
                 kkt_residual(p, k, fix, sd, sc, k->rhs_c, dtau, k->w2, k->lam2, k->nuf2, k->z2, k->ed, k->edyn, k->ec);
                 kkt_solve(p, k, fix, k->ed, NULL, k->edyn, 0, k->ec, k->w1, k->lam1, k->nuf1, k->z1); /* v1 no longer needed */

@@ -39,6 +39,7 @@
 #define WAVE 64
 // active-set polish (same constants as oracle/hsde_qp.c): penalty of the active rows, proximal weight of the
 // inactive rows (must stay above eps * rho), multiplier steps per active set, active sets per attempt
+#define HMPC_REFINE_FROM_IT 12
 #define HMPC_POLISH_RHO 1e5
 #define HMPC_POLISH_RHO2 1e7 // second level, for active sets whose multiplier steps do not settle at the first
 #define HMPC_POLISH_DELTA 1e-10
@@ -666,6 +667,8 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 #define LM_STAGE(nx, nu) ((nx) * (nu) + (nu) * ((nu) - 1) / 2)
 #define LM_X(nx, nu, x, j) ((x) * (nu) + (j))                       /* state row x, pivot j     */
 #define LM_U(nx, nu, i, j) ((nx) * (nu) + (i) * ((i) - 1) / 2 + (j)) /* input row i, pivot j < i */
+
+template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, int lane, int t, const ldsd *Pn, int pns);
 
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
@@ -1675,8 +1678,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // active set, with factorisation; mode 2: a further multiplier step with the factorisation at hand): the
     // polish reuses the factorisation and the constant-direction solve below instead of owning copies of them.
     int mode = 0, round = 0, al = 0;
-    double rho = HMPC_POLISH_RHO; // penalty of the polish in progress
-    int level = 0;                // 0: first penalty level; 1: second; 2: back at the first for the last digits
+    int level = 0; // penalty of the polish in progress: 0 first level; 1 second; 2 back at the first for the last digits
+#define HMPC_RHO_OF(level) ((level) == 1 ? HMPC_POLISH_RHO2 : HMPC_POLISH_RHO)
     double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
     for (it = 0; it <= p.max_iter;) {
       if (mode == 0) {
@@ -1857,14 +1860,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 if (zr != 0.0) {
                     const bool active = zr > R.s(k, rw.e) || ((amask >> (k & 63)) & 1ull);
                     R.prod(k, rw.e) = zr; // kept for the way back
-                    if (active) { d = rho; R.dz(k, rw.e) = zr / tau; }
+                    if (active) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
                     else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
                     R.D(k, rw.e) = d;
                 }
                 S.e[rw.e] = d;
             ROWS_END
             mode = 1; round = 0; al = 0;
-            rho = HMPC_POLISH_RHO;
             level = 0;
             attempts++;
         } else {
@@ -1935,65 +1937,69 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     double v[2] = {pinf, pmove};
                     const int op[2] = {1, 1};
                     block_reduce<D, 2>(v, op, S.red, lane);
-                    pinf = v[0] / rho; pmove = v[1];
+                    pinf = v[0] / HMPC_RHO_OF(level); pmove = v[1];
                 }
                 if (!((al >= 1 && pinf <= 1e-12 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-13) || al == HMPC_POLISH_ITERS - 1)) {
                     al++;
                     mode = 2;
                     outcome = 2;
-                } else if (pinf <= (level == 0 ? 1e-12 : 1e-10) * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-12 * (1 + zinf / tau)) {
-                    // (otherwise give up: the active rows are not met, or the proximal term -- dropped from the
-                    // multipliers, hence the stationarity residual of the result -- has not died out)
-                    // Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides,
-                    // but only those within a factor two of the worst violation / the most negative multiplier (a
-                    // missing active row drags others across their bounds; the next round shows which are real).
-                    // (the sign test is absolute and tight: a clipped negative multiplier costs |z| / curvature of the
-                    // stage cost in the trajectory, a violated inactive row only its violation)
-                    const double ez = 1e-11, es = 1e-9 * (1 + winf / tau);
+                } else {
+                    // what next: -1 give up, 0 verified, 1 rows on the wrong side change sides, 2 other penalty level
+                    int act = -1;
                     double vmax = 0, zmin = 0;
-                    ROWS_BEGIN(k, rw)
-                        const double d = R.D(k, rw.e);
-                        if (d >= 1.0) zmin = fmin(zmin, R.dz(k, rw.e));
-                        else if (d != 0.0) vmax = fmax(vmax, R.dz(k, rw.e) - rm.h(p, S, k, rw));
-                    ROWS_END
-                    {
-                        double v[2] = {vmax, zmin};
-                        const int op[2] = {1, 2};
-                        block_reduce<D, 2>(v, op, S.red, lane);
-                        vmax = v[0]; zmin = v[1];
-                    }
-                    if (vmax <= es && zmin >= -ez) {
-                        if (level == 1 && round + 1 < HMPC_POLISH_ROUNDS) {
-                            // verified at the second level: the same active set once more at the first, from these
+                    const double ez = 1e-11, es = 1e-9 * (1 + winf / tau);
+                    if (pinf <= (level == 0 ? 1e-12 : 1e-10) * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-12 * (1 + zinf / tau)) {
+                        // The active rows are met and the proximal term -- dropped from the multipliers, hence the
+                        // stationarity residual of the result -- has died out.  Sign of the multipliers, slack of the
+                        // inactive rows: the sign test is absolute and tight (a clipped negative multiplier costs |z| /
+                        // curvature of the stage cost in the trajectory, a violated inactive row only its violation).
+                        ROWS_BEGIN(k, rw)
+                            const double d = R.D(k, rw.e);
+                            if (d >= 1.0) zmin = fmin(zmin, R.dz(k, rw.e));
+                            else if (d != 0.0) vmax = fmax(vmax, R.dz(k, rw.e) - rm.h(p, S, k, rw));
+                        ROWS_END
+                        {
+                            double v[2] = {vmax, zmin};
+                            const int op[2] = {1, 2};
+                            block_reduce<D, 2>(v, op, S.red, lane);
+                            vmax = v[0]; zmin = v[1];
+                        }
+                        if (vmax <= es && zmin >= -ez) {
+                            // verified; at the second level: the same active set once more at the first, from these
                             // multipliers (what is left to settle are the components that matter, of the size of the
                             // second level's rounding; the slow ones are in place)
-                            level = 2;
-                            rho = HMPC_POLISH_RHO;
-                            round++;
-                            ROWS_BEGIN(k, rw)
-                                double d = R.D(k, rw.e);
-                                if (d >= 1.0) { d = rho; R.D(k, rw.e) = d; }
-                                else if (d != 0.0) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
-                                S.e[rw.e] = d;
-                            ROWS_END
-                            __syncthreads();
-                            al = 0;
-                            mode = 1;
-                            outcome = 2;
-                        } else {
-                            outcome = 1;
+                            act = (level == 1 && round + 1 < HMPC_POLISH_ROUNDS) ? 2 : 0;
+                        } else if (round + 1 < HMPC_POLISH_ROUNDS) {
+                            // Rows on the wrong side change sides, but only those within a factor two of the worst
+                            // violation / the most negative multiplier (a missing active row drags others across their
+                            // bounds; the next round shows which are real).
+                            act = 1;
                         }
-                    } else if (++round < HMPC_POLISH_ROUNDS) {
+                    } else if (level == 0 && pinf == pinf && round + 1 < HMPC_POLISH_ROUNDS) {
+                        // The multiplier steps contract by 1 / (1 + rho lambda), lambda the eigenvalues of C_A Phi^-1 C_A':
+                        // active rows that nearly depend on each other do not settle at the first level.  They do at the
+                        // second -- not the first choice: eps rho is no longer below the proximal weight there (1e-9 in the
+                        // multipliers, ~1e-6 in the trajectory) --, used once per attempt where the first fails; its result
+                        // goes through the first level once more (level 2).  Same as oracle/hsde_qp.c polish().
+                        act = 2;
+                    }
+                    if (act == 0) {
+                        outcome = 1;
+                    } else if (act > 0) {
+                        if (act == 2) level++;
+                        const double rho = HMPC_RHO_OF(level);
+                        const bool flip = act == 1;
+                        round++;
                         ROWS_BEGIN(k, rw)
                             double d = R.D(k, rw.e);
                             if (d != 0.0) {
                                 if (d < 1.0) {
-                                    if (vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = rho; R.dz(k, rw.e) = 0.0; }
-                                } else if (zmin < -ez && R.dz(k, rw.e) < 0.5 * zmin) {
-                                    d = HMPC_POLISH_DELTA;
+                                    if (flip && vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = rho; R.dz(k, rw.e) = 0.0; }
+                                } else {
+                                    d = (flip && zmin < -ez && R.dz(k, rw.e) < 0.5 * zmin) ? HMPC_POLISH_DELTA : rho;
                                 }
                                 R.D(k, rw.e) = d;
-                                // next active set: the proximal centre starts at the interior-point iterate again
+                                // next pass: the proximal centre starts at the interior-point iterate again
                                 if (d == HMPC_POLISH_DELTA) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
                             }
                             S.e[rw.e] = d;
@@ -2003,24 +2009,6 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         mode = 1;
                         outcome = 2;
                     }
-                } else if (level == 0 && pinf == pinf && ++round < HMPC_POLISH_ROUNDS) {
-                    // The multiplier steps contract by 1 / (1 + rho lambda), lambda the eigenvalues of C_A Phi^-1 C_A':
-                    // active rows that nearly depend on each other do not settle at the first level.  They do at the
-                    // second -- not the first choice: eps rho is no longer below the proximal weight there (1e-9 in the
-                    // multipliers, ~1e-6 in the trajectory) --, used once per attempt where the first fails; its result
-                    // goes through the first level once more (level 2).  Same as oracle/hsde_qp.c polish().
-                    level = 1;
-                    rho = HMPC_POLISH_RHO2;
-                    ROWS_BEGIN(k, rw)
-                        double d = R.D(k, rw.e);
-                        if (d >= 1.0) { d = rho; R.D(k, rw.e) = d; }
-                        else if (d != 0.0) R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau;
-                        S.e[rw.e] = d;
-                    ROWS_END
-                    __syncthreads();
-                    al = 0;
-                    mode = 1;
-                    outcome = 2;
                 }
             }
             if (outcome == 2) continue;
@@ -2112,7 +2100,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             // one step once mu < 1e-3, two once mu < 1e-7 (one step squares the relative error of a
             // solve; the stage cost's small curvature needs the dual residual well below the stopping
             // tolerance for the trajectory to be accurate to 1e-5).
-            const int nref = (pass == 1 && p.refine) ? (mu < 1e-7 ? 2 : mu < 1e-3 ? 1 : 0) : 0;
+            // (Refinement from iteration HMPC_REFINE_FROM_IT on, or once a polish has been tried and did not verify -- from
+            // then on the iterate itself may be the answer.  The nodes that end before, nearly all, take the same
+            // iterations with and without it and return the polished point or a ray: measured, 6.46 -> 6.12 ms.)
+            const int nref = (pass == 1 && p.refine && (it >= HMPC_REFINE_FROM_IT || attempts > 0 || !p.polish)) ? (mu < 1e-7 ? 2 : mu < 1e-3 ? 1 : 0) : 0;
             for (int rf = 0; rf < nref; rf++) {
                 LANE_OPAQUE(lane);
                 if (rf > 0) { // S.e <- current dz for the C' dz products (the previous round left its correction there)
