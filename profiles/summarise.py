@@ -18,10 +18,12 @@ import sys
 
 
 def find(d, suffix):
-    hits = sorted(glob.glob(os.path.join(d, '**', '*' + suffix), recursive=True))
+    """Files of the NEWEST run in the directory: gpurun merges the box's output into the local directory of the same
+    name, so a directory that was collected twice holds both runs (one process-id prefix each)."""
+    hits = sorted(glob.glob(os.path.join(d, '**', '*' + suffix), recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit('no *%s under %s' % (suffix, d))
-    return hits
+    return hits[-1:]
 
 
 def stats(d, out):

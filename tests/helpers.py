@@ -55,6 +55,22 @@ def random_prefix_frontier(T, nub, count, p_one=0.5, seed0=1000):
     return fix
 
 
+def shallow_wide_family(name, T, count, width, depth=30, p_one=.15, seed=3):
+    """Nodes with few fixed binaries (prefix length ~ U{0..depth-1}, Bernoulli(p_one) values) and one initial state per
+    node, uniform over ``width`` of the state box: feasible-heavy, and -- for the one-wall system at N=40 -- home of the
+    active sets whose multiplier steps need the second penalty level of the polish (terminal-set facets next to the
+    state bounds they come from).  Returns (x0 [count, nx], fix [count, T nub])."""
+    d = load_fixture(name)
+    nub = int(d['nub'])
+    rng = np.random.RandomState(seed)
+    fix = np.full((count, T * nub), -1, np.int8)
+    for k in range(count):
+        dep = rng.randint(0, depth)
+        fix[k, :dep] = rng.rand(dep) < p_one
+    x0 = (rng.rand(count, d['A'].shape[0]) - .5) * 2 * d['x_max'] * width
+    return x0, fix
+
+
 def random_mld(nx=20, nuc=6, nub=8, seed=0):
     """Random MLD of SURVEY.md 8(d) C4 (a build decision, BASELINE.json leaves the rows open):
     stable A, box rows on x and uc, four big-M rows per binary."""

@@ -102,6 +102,28 @@ def test_every_kernel_instantiation(monkeypatch, fixture, T, waves):
     _compare(hip, res, orc.qp.solve_batch(X0, fix), T, fix)
 
 
+def test_shallow_wide_family_polishes_everywhere():
+    # the nodes whose active sets need the second penalty level of the polish (see the CPU test of the same family):
+    # kernel == oracle at RTOL, every optimal node polished on both sides, and the kernel's records against the dense
+    # active-set solve, which shares no code with either
+    from helpers import shallow_wide_family
+    from dense_qp import dense_qp, active_set_primal
+    x0, fix = shallow_wide_family('cart_pole_one_wall', 40, 4000, .6)
+    hip = make_controller('cart_pole_one_wall', T=40, backend='hip')
+    orc = make_controller('cart_pole_one_wall', T=40, backend='oracle', threads=8)
+    a, b = hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix)
+    _compare(hip, a, b, 40, fix)
+    opt = np.flatnonzero(a['status'] == 0)
+    assert opt.size > 300 and np.all(a['polished'][opt] > 0)
+    dq = dense_qp(hip)
+    late = opt[np.argsort(-(a['iters'][opt] & 0xFFFF))][:40]
+    for i in np.concatenate((late, opt[:40])):
+        w, resid = active_set_primal(hip, dq, x0[i], fix[i], a['dual'][i])
+        n = 41 * 4
+        assert resid < 1e-10
+        assert np.max(np.abs(w[:n] - a['primal'][i][:n])) / max(1e-2, np.max(np.abs(w[:n]))) < 1e-7
+
+
 def test_generic_kernel_forced_on_cart_pole(monkeypatch):
     # the run-time-sized kernel (list row map, LDS factor) on the reference's system
     monkeypatch.setenv('HMPC_FORCE_GENERIC', '1')

@@ -173,6 +173,28 @@ def test_trajectories_against_dense_active_set_solve():
     assert worst_raw < 1e-3          # (what the polish is for: measured 4e-5 on this set)
 
 
+def test_polish_settles_nearly_dependent_active_sets():
+    # one-wall system, N=40, initial states over 60 % of the state box: ~2 % of the feasible nodes have active sets
+    # (terminal-set facets next to the state bounds they were pushed through the dynamics from) on which the multiplier
+    # steps do not settle at the first penalty level; with the second level every optimal node polishes, and the result
+    # is the solution of the dense active-set solve
+    from helpers import shallow_wide_family
+    from dense_qp import dense_qp, active_set_primal
+    x0, fix = shallow_wide_family('cart_pole_one_wall', 40, 4000, .6)
+    ctrl = make_controller('cart_pole_one_wall', T=40, backend='oracle', threads=8)
+    res = ctrl.qp.solve_batch(x0, fix)
+    assert np.all(res['status'] <= 1)
+    opt = np.flatnonzero(res['status'] == 0)
+    assert opt.size > 300 and np.all(res['polished'][opt] > 0), (opt.size, int((res['polished'][opt] == 0).sum()))
+    dq = dense_qp(ctrl)
+    late = opt[np.argsort(-(res['iters'][opt] & 0xFFFF))][:40]          # the nodes that needed most iterations
+    for b in np.concatenate((late, opt[:40])):
+        w, resid = active_set_primal(ctrl, dq, x0[b], fix[b], res['dual'][b])
+        n = 41 * 4
+        assert resid < 1e-10
+        assert np.max(np.abs(w[:n] - res['primal'][b][:n])) / max(1e-2, np.max(np.abs(w[:n]))) < 1e-7
+
+
 def test_product_configuration_against_the_tight_one():
     # The product polishes from an iterate that is only good to 1e-4; the result must still be THE vertex solution.
     # Random prefixes with one initial state per node; this set holds nodes on which a clipped multiplier of -5e-8
