@@ -42,6 +42,14 @@ static __device__ __forceinline__ double shift_wave_sum(double v)
 #ifndef SHIFT_WAVES
 #define SHIFT_WAVES 4
 #endif
+// loads in flight per lane in a copy batch (16 needs more than the 128 registers of 4 waves per SIMD: spills)
+#ifndef SHIFT_CU
+#define SHIFT_CU 8
+#endif
+// register slots (x 64 lanes) for the head of a row: old last stage of mu, identifier
+#ifndef SHIFT_HEAD_SLOTS
+#define SHIFT_HEAD_SLOTS 3
+#endif
 #ifndef HMPC_SHIFT_ATTR
 #define HMPC_SHIFT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
@@ -85,8 +93,17 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
     }
     __syncthreads();
     const int half = lane >= 32 ? 1 : 0, hl = lane & 31; // two half-waves split the long sums
-    for (int b = blockIdx.x * SHIFT_WAVES + wave; b < a.B; b += gridDim.x * SHIFT_WAVES) {
-        const int own = a.owner[b];
+    // the head of the NEXT leaf (owner, the binaries it fixes at time 0) is fetched while the current one is shifted
+    const int stride = gridDim.x * SHIFT_WAVES;
+    int b = blockIdx.x * SHIFT_WAVES + wave;
+    int own_n = b < a.B ? a.owner[b] : 0;
+    int fix_n = (b < a.B && lane < nub) ? a.fix[(size_t)b * T * nub + lane] : -1;
+    for (; b < a.B; b += stride) {
+        const int own = own_n, fix_lane = fix_n;
+        if (b + stride < a.B) {
+            own_n = a.owner[b + stride];
+            fix_n = lane < nub ? a.fix[(size_t)(b + stride) * T * nub + lane] : -1;
+        }
         const double *x0g = a.x0 + (size_t)own * nx, *u0g = a.u0 + (size_t)own * nu, *e0 = a.e0 + (size_t)own * nx;
         const int8_t *fix = a.fix + (size_t)b * T * nub;
         const size_t srow = a.src ? (size_t)a.src[b] : (size_t)b;
@@ -94,20 +111,32 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
         double *o = a.dual_out + (size_t)b * p.n_dual;
         // retain rule (controller.py:566-613): the binaries the leaf fixes at time 0 are the applied ones
         int agree = 1;
-        if (lane < nub) {
-            const int f = fix[lane];
-            agree = f < 0 || f == (int)rint(u0g[nuc + lane]);
-        }
+        if (lane < nub) agree = fix_lane < 0 || fix_lane == (int)rint(u0g[nuc + lane]);
         agree = __all(agree);
         if (!agree) { // dropped: nothing else is defined for this leaf
             if (lane == 0) a.flags[b] = 0;
             continue;
         }
-        // the old last stage goes to LDS (read by every lane below), everything else straight through
-        for (int k = lane; k < ncL; k += 64) muL[k] = d[o_mu + (T - 1) * nc + k];
-        for (int k = lane; k < nqT; k += 64) rhoT[k] = d[o_rho + T * nq + k];
-        for (int j = lane; j < nx; j += 64) xs[j] = x0g[j];
-        for (int j = lane; j < nu; j += 64) us[j] = u0g[j];
+        // The head of the row: the old last stage goes to LDS (read by every lane below), the identifier moves one stage.
+        // Same rule as for the copy below: a loop "load, use" with a run-time trip count waits for the memory once per
+        // trip, and a load or store under a lane predicate makes every later one wait for everything before it -- so
+        // batches of SHIFT_HEAD_SLOTS x 64 entries from clamped indices (lanes beyond the end repeat the last entry).
+        {
+            const double *dL = d + o_mu + (T - 1) * nc;
+            // (the first 64 entries of rho_T, x0, u0 travel with the first batch)
+            const double rv = d[o_rho + T * nq + min(lane, nqT - 1)], xv = x0g[min(lane, nx - 1)], uv = u0g[min(lane, nu - 1)];
+            for (int k0 = 0; k0 < ncL; k0 += 64 * SHIFT_HEAD_SLOTS) {
+                double mh[SHIFT_HEAD_SLOTS];
+#pragma unroll
+                for (int u = 0; u < SHIFT_HEAD_SLOTS; u++) mh[u] = dL[min(k0 + u * 64 + lane, ncL - 1)];
+#pragma unroll
+                for (int u = 0; u < SHIFT_HEAD_SLOTS; u++) muL[min(k0 + u * 64 + lane, ncL - 1)] = mh[u];
+            }
+            rhoT[min(lane, nqT - 1)] = rv; xs[min(lane, nx - 1)] = xv; us[min(lane, nu - 1)] = uv;
+        }
+        for (int k = lane + 64; k < nqT; k += 64) rhoT[k] = d[o_rho + T * nq + k];
+        for (int j = lane + 64; j < nx; j += 64) xs[j] = x0g[j];
+        for (int j = lane + 64; j < nu; j += 64) us[j] = u0g[j];
         const double *x0 = xs, *u0 = us; // LDS copies: every dot product below reads them
         // the time-0 entries the pi-sum needs are not part of the copy below: fetch them now, so that after the
         // copy nothing waits on global memory any more
@@ -115,23 +144,41 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
         const double rho0 = lane < nq ? d[o_rho + lane] : 0.0, sig0 = lane < nr ? d[o_sig + lane] : 0.0;
         const double nulb0 = lane < nub ? d[o_lb + lane] : 0.0, nuub0 = lane < nub ? d[o_ub + lane] : 0.0;
         const double lam1 = lane < nx ? d[nx + lane] : 0.0, e0v = lane < nx ? e0[lane] : 0.0;
-        const int fix0 = lane < nub ? fix[lane] : -1;
+        const int fix0 = fix_lane;
         const double dobj_in = a.dobj[srow], lb_in = a.lb[b];
         // identifier: drop time 0, the stage that enters is free
-        int8_t *fo = a.fix_out + (size_t)b * T * nub;
-        for (int i = lane; i < T * nub; i += 64) fo[i] = i < (T - 1) * nub ? fix[i + nub] : (int8_t)-1;
+        {
+            int8_t *fo = a.fix_out + (size_t)b * T * nub;
+            const int nfix = T * nub;
+            for (int i0 = 0; i0 < nfix; i0 += 64 * SHIFT_HEAD_SLOTS) {
+                int fb[SHIFT_HEAD_SLOTS];
+#pragma unroll
+                for (int u = 0; u < SHIFT_HEAD_SLOTS; u++) fb[u] = fix[min(i0 + u * 64 + lane + nub, nfix - 1)];
+#pragma unroll
+                for (int u = 0; u < SHIFT_HEAD_SLOTS; u++) {
+                    const int i = min(i0 + u * 64 + lane, nfix - 1);
+                    fo[i] = i < (T - 1) * nub ? (int8_t)fb[u] : (int8_t)-1;
+                }
+            }
+        }
         // multipliers: everything moves one stage towards the present, the end is padded with zeros
-        // (controller.py:615-666).  One pass over the output row, sixteen independent loads per lane in flight (8 KB per wave:
-        // what it takes to keep HBM busy at ~2 us latency);
+        // (controller.py:615-666).  One pass over the output row, SHIFT_CU independent loads per lane in flight;
         // the two blocks that come from the maps (mu'_{T-2}, rho'_{T-1}) are written further down.
         const int e_mu1 = o_mu + (T - 2) * nc, e_mu2 = o_mu + (T - 1) * nc, e_rho1 = o_rho + (T - 1) * nq, e_rho2 = o_rho + T * nq;
-        constexpr int CU_ = 16;
+        // A store under a lane predicate sits in a branch of its own; the wait counter then cannot tell how many memory
+        // operations are outstanding and every one of the stores waits for ALL earlier ones, loads and stores, to
+        // complete: a batch of eight stores paid eight write acknowledgements one after the other.  So the copy is free of
+        // predicates: loads from a clamped index with the value selected afterwards, unconditional stores -- the two
+        // mapped blocks receive zeros first and their values after the release fence below.
+        constexpr int CU_ = SHIFT_CU;
+        const int i_last = p.n_dual - 1;
         for (int i0 = 0; i0 < p.n_dual; i0 += 64 * CU_) {
-            int src[CU_];
+            int src[CU_], dst[CU_];
             double v[CU_];
 #pragma unroll
             for (int u = 0; u < CU_; u++) {
-                const int i = i0 + u * 64 + lane;
+                // lanes beyond the end of the row repeat its last entry (same value to the same address: no predicate)
+                const int i = min(i0 + u * 64 + lane, i_last);
                 int sft, lim; // source = i + sft while i < lim, zero from lim to the end of the segment
                 if (i < o_mu) { sft = nx; lim = T * nx; }
                 else if (i < o_lb) { sft = nc; lim = e_mu1; }
@@ -140,14 +187,15 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
                 else if (i < o_sig) { sft = nq; lim = e_rho1; }
                 else { sft = nr; lim = o_sig + (T - 1) * nr; }
                 const bool mapped = (i >= e_mu1 && i < e_mu2) || (i >= e_rho1 && i < e_rho2);
-                src[u] = (i >= p.n_dual || mapped) ? -2 : i < lim ? i + sft : -1;
+                src[u] = (!mapped && i < lim) ? i + sft : -1;
+                dst[u] = i;
             }
 #pragma unroll
-            for (int u = 0; u < CU_; u++) v[u] = src[u] >= 0 ? d[src[u]] : 0.0;
+            for (int u = 0; u < CU_; u++) { const double t = d[max(src[u], 0)]; v[u] = src[u] >= 0 ? t : 0.0; }
 #pragma unroll
-            for (int u = 0; u < CU_; u++)
-                if (src[u] != -2) o[i0 + u * 64 + lane] = v[u];
+            for (int u = 0; u < CU_; u++) o[dst[u]] = v[u];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // the zeros of the mapped blocks are out before their values
         __builtin_amdgcn_wave_barrier(); // muL / rhoT written by this wave are read by all its lanes below
         double acc = 0.0; // every lane's share of the pi-sum (controller.py:668-721)
         // mu'_{T-2} = M_mu mu_{T-1}: rows in chunks of 32, each half-wave sums half of the columns
