@@ -36,9 +36,13 @@ static __device__ __forceinline__ double shift_wave_sum(double v)
 }
 
 // Waves per workgroup: the workgroup stages the maps once and every wave shifts one leaf at a time.
-// Measured on MI355X (65 536 leaves): 8 waves per workgroup at the compiler's 163 registers -> one workgroup per CU,
-// 2.12 TB/s; 4 waves per workgroup held to 128 registers (4 waves per SIMD, 4 workgroups per CU) -> 2.55 TB/s;
-// 5 or more waves per SIMD spill and lose (1.7 TB/s and below).
+// The kernel is bound by the latency of a wave's own chain of memory round trips, so its rate is waves in flight divided
+// by round trips per leaf.  Measured on MI355X (65 536 leaves):
+//   8 waves per workgroup at the compiler's 163 registers -> one workgroup per CU                      2.12 TB/s
+//   4 waves per workgroup held to 128 registers (4 waves per SIMD, 4 workgroups per CU), 36 spilled    2.46-2.55 TB/s
+//   the same without spills (8 instead of 16 loads in flight per lane)                                 2.97 TB/s
+//   no load or store under a lane predicate in the copy (see there), heads batched and prefetched      3.78 TB/s
+//   (262 144 leaves: 4.44 TB/s = 55 % of the HBM peak); 3 waves per SIMD: 2.68, 5 and more spill: < 1.9.
 #ifndef SHIFT_WAVES
 #define SHIFT_WAVES 4
 #endif
