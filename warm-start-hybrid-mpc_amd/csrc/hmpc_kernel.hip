@@ -694,6 +694,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
             // dense contractions on the matrix cores; P_{t+1} is still where the previous stage's elimination
             // left it (the leading nx x nx block of S.Mm), the terminal Hessian for the last stage
             stage_matrix_mfma<D>(p, S, lane, t, t == T - 1 ? S.PT : S.Mm, t == T - 1 ? nx : nz);
+            FSTAMP(0);
         } else {
         // M = P + C' D C (sparse Gram lists) ; PA = Pn [A B]
         for (int e = lane; e < ne; e += D::kNT) {
