@@ -58,3 +58,33 @@ def test_product_path_fails_loudly_without_gpu():
     mld = MLDSystem([d['A'], d['B']], [d['F'], d['G'], d['h']], int(d['nub']))
     with pytest.raises(RuntimeError):
         HybridModelPredictiveController(mld, 10, [d['Q'], d['R'], d['Q_T']], None)
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    from warm_start_hmpc_amd.qp_backend import LIBRARY_PATH
+    exe = str(tmp_path / 'c_abi_example')
+    libdir = os.path.dirname(LIBRARY_PATH)
+    cmd = ['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'examples', 'c_abi_example.c'), '-L', libdir, '-lhmpc', '-Wl,-rpath,' + libdir, '-lm', '-o', exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+@pytest.mark.skipif(_has_gpu(), reason='only meaningful on a box without a GPU')
+def test_header_is_plain_c_and_a_c_caller_fails_loudly_without_gpu(tmp_path):
+    # include/hmpc.h is the boundary for callers in any language: it must compile as strict C99, and a C program linked
+    # against libhmpc.so must get an error code and a message -- not a crash, not a CPU answer -- where there is no GPU
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and 'hmpc_create' in r.stderr, (r.returncode, r.stderr)
+
+
+@pytest.mark.gpu
+def test_c_caller_gets_the_known_answers(tmp_path):
+    # examples/c_abi_example.c: create / solve three nodes / infeasible node / facet LPs / destroy from plain C
+    import subprocess
+    exe = _build_c_example(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'c_abi_example: ok' in r.stdout, (r.returncode, r.stdout, r.stderr)
