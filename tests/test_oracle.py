@@ -173,6 +173,36 @@ def test_trajectories_against_dense_active_set_solve():
     assert worst_raw < 1e-3          # (what the polish is for: measured 4e-5 on this set)
 
 
+def test_root_relaxations_against_an_independent_qp_solver():
+    # scipy's trust-constr (Byrd-Hribar-Nocedal interior point; no code, factorisation or active-set logic in common with
+    # the oracle or the kernel) on the dense statement of the node QP (tests/dense_qp.py): the root relaxation of the
+    # N=10 case from two initial states.  (~7 s each; on nodes with fixed binaries its equality-constrained SQP meets a
+    # singular Jacobian and takes minutes to reach 1e-6 -- those are pinned by the dense active-set solve instead.)
+    from scipy.optimize import minimize, LinearConstraint, Bounds
+    from dense_qp import dense_qp
+    T, nx, nu, nub = 10, 4, 7, 4
+    ctrl = make_controller('cart_pole_with_walls', T=T, backend='oracle')
+    H, E, C, h = dense_qp(ctrl)
+    n = H.shape[0]
+    lo, hi = np.full(n, -np.inf), np.full(n, np.inf)
+    for t in range(T):
+        for b in range(nub):
+            lo[(T + 1) * nx + t * nu + (nu - nub) + b], hi[(T + 1) * nx + t * nu + (nu - nub) + b] = 0., 1.
+    fix = np.full((1, T * nub), -1, np.int8)
+    for x0 in (np.array([0., 0., .5, 0.]), np.array([.1, -.05, .4, .2])):
+        res = ctrl.qp.solve_batch(x0, fix)
+        assert res['status'][0] == 0 and res['polished'][0] > 0
+        beq = np.zeros(E.shape[0])
+        beq[:nx] = x0
+        ref = minimize(lambda w: .5 * w @ H @ w, np.zeros(n), jac=lambda w: H @ w, hess=lambda w: H, method='trust-constr',
+                       constraints=[LinearConstraint(E, beq, beq), LinearConstraint(C, -np.inf, h)], bounds=Bounds(lo, hi),
+                       options=dict(gtol=1e-12, xtol=1e-14, barrier_tol=1e-12, maxiter=3000))
+        assert np.max(C @ ref.x - h) < 1e-9 and np.max(np.abs(E @ ref.x - beq)) < 1e-9
+        np.testing.assert_allclose(res['obj'][0], ref.fun, rtol=1e-9)                     # (measured 2e-15)
+        X, Xr = res['primal'][0][:(T + 1) * nx], ref.x[:(T + 1) * nx]
+        assert np.max(np.abs(X - Xr)) / max(1e-2, np.max(np.abs(Xr))) < 1e-6              # (measured 1.3e-8)
+
+
 def test_polish_settles_nearly_dependent_active_sets():
     # one-wall system, N=40, initial states over 60 % of the state box: ~2 % of the feasible nodes have active sets
     # (terminal-set facets next to the state bounds they were pushed through the dynamics from) on which the multiplier
