@@ -5,12 +5,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import conftest  # noqa
 import numpy as np
 from helpers import make_controller, random_prefix_frontier
-T = 20
-hip = make_controller('cart_pole_with_walls', T=T, backend='hip')
-orc = make_controller('cart_pole_with_walls', T=T, backend='oracle', threads=16)
+# DBG_SYSTEM / DBG_T select the system and horizon of the random-depth family (default: the headline system, N=20);
+# DBG_REPS the number of frontiers; DBG_SKIP_WIDE=1 leaves the second family out
+NAME = os.environ.get('DBG_SYSTEM', 'cart_pole_with_walls')
+T = int(os.environ.get('DBG_T', 20))
+hip = make_controller(NAME, T=T, backend='hip')
+orc = make_controller(NAME, T=T, backend='oracle', threads=16)
 # the oracle run tighter than the product (tol 1e-10, polish from a converged iterate): kernel and default oracle are the same
 # algorithm, a defect they share shows only against this one
-tight = make_controller('cart_pole_with_walls', T=T, backend='oracle', threads=16, tol=1e-10, polish_tol=1e-8)
+tight = make_controller(NAME, T=T, backend='oracle', threads=16, tol=1e-10, polish_tol=1e-8)
+NUB, NU = hip.mld.nub, hip.mld.nu
 rng = np.random.default_rng(123)
 tot = bad_status = unpolished = 0
 worst = worst_fc = worst_tight = 0.
@@ -18,7 +22,7 @@ nbig = nbig_tight = 0
 for rep in range(int(os.environ.get('DBG_REPS', 24))):
     B = int(rng.choice([64, 300, 700, 2048, 4096]))
     p_one = float(rng.choice([0.02, 0.1, 0.3, 0.5]))
-    fix = random_prefix_frontier(T, 4, B, p_one=p_one, seed0=100000 + 5000 * rep)
+    fix = random_prefix_frontier(T, NUB, B, p_one=p_one, seed0=100000 + 5000 * rep)
     x0 = rng.uniform(-1, 1, (B, 4)) * np.array([.3, .2, 1.0, .8])
     a, b = hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix)
     tot += B
@@ -30,7 +34,7 @@ for rep in range(int(os.environ.get('DBG_REPS', 24))):
         dev = np.max(np.abs(xa - xb), axis=1) / np.maximum(1e-2, np.max(np.abs(xb), axis=1))
         worst = max(worst, float(dev.max()))
         nbig += int((dev > 1e-5).sum())
-        fa, fb = a['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, 7)[:, :, 0], b['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, 7)[:, :, 0]
+        fa, fb = a['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, NU)[:, :, 0], b['primal'][fin][:, (T + 1) * 4:].reshape(-1, T, NU)[:, :, 0]
         worst_fc = max(worst_fc, float((np.max(np.abs(fa - fb), axis=1) / np.maximum(1e-2, np.max(np.abs(fb), axis=1))).max()))
         unpolished += int((a['polished'][fin] == 0).sum())
         c = tight.qp.solve_batch(x0, fix)
@@ -40,6 +44,7 @@ for rep in range(int(os.environ.get('DBG_REPS', 24))):
         nbig_tight += int((devt > 1e-5).sum())
     print('rep %2d B %4d p %.2f: status mismatches %d, not converged hip %d oracle %d, feasible %d, worst dev so far %.1e, > 1e-5: %d'
           % (rep, B, p_one, ns, int((a['status'] > 1).sum()), int((b['status'] > 1).sum()), int(fin.sum()), worst, nbig), flush=True)
+print('%s N=%d: ' % (NAME, T), end='')
 print('TOTAL nodes %d, status mismatches %d, worst state-trajectory deviation %.2e (penalised input %.2e), nodes above 1e-5: %d, optimal nodes left unpolished by the kernel: %d'
       % (tot, bad_status, worst, worst_fc, nbig, unpolished))
 print('against the tight oracle: worst deviation %.2e, nodes above 1e-5: %d' % (worst_tight, nbig_tight))
@@ -48,7 +53,7 @@ print('against the tight oracle: worst deviation %.2e, nodes above 1e-5: %d' % (
 # penalty level of the polish live here), every system; the kernel against the oracle and -- independent of both --
 # against the dense active-set solve of tests/dense_qp.py on the first 300 optimal nodes of each batch
 import dense_qp
-for name, T2, B, width, depth, p1 in (('cart_pole_one_wall', 40, 12000, .6, 30, .15), ('cart_pole_with_walls', 20, 6000, .5, 40, .3),
+for name, T2, B, width, depth, p1 in () if os.environ.get('DBG_SKIP_WIDE') else (('cart_pole_one_wall', 40, 12000, .6, 30, .15), ('cart_pole_with_walls', 20, 6000, .5, 40, .3),
                                      ('cart_pole_with_walls', 40, 3000, .5, 40, .3)):
     h2 = make_controller(name, T=T2, backend='hip')
     o2 = make_controller(name, T=T2, backend='oracle', threads=16)

@@ -1789,14 +1789,20 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             // default): nothing more can be gained from the interior-point iteration on an interior-free node
             const bool exhausted = status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
                                    rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol;
-            polish = p.polish && !tried && attempts < HMPC_POLISH_ATTEMPTS &&
-                     (acceptable || exhausted || (status != HMPC_OPTIMAL && rcinf / tau <= p.ptol * (1 + winf / tau + x0inf) &&
-                                                  rdinf / tau <= p.ptol * (1 + zinf / tau) && gap <= gptol));
+            // (the iterate this solve would return gets one last attempt even when the regular ones are used up -- they were
+            // spent on immature iterates; 5 of 4 000 optimal nodes of the one-wall system at N=40 ended that way)
+            const bool desired = gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * p.tol * (1 + zinf / tau);
+            const bool final_exit = (acceptable && (desired || extra_done >= 3 || it == p.max_iter)) || exhausted;
+            polish = p.polish && !tried &&
+                     (attempts < HMPC_POLISH_ATTEMPTS
+                          ? (acceptable || exhausted || (status != HMPC_OPTIMAL && rcinf / tau <= p.ptol * (1 + winf / tau + x0inf) &&
+                                                         rdinf / tau <= p.ptol * (1 + zinf / tau) && gap <= gptol))
+                          : (attempts == HMPC_POLISH_ATTEMPTS && final_exit));
             if (polish) {
                 // decided by the passes of the polish
             } else if (acceptable) {
                 status = HMPC_OPTIMAL;
-                if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * p.tol * (1 + zinf / tau)) || extra_done >= 3 || it == p.max_iter) break;
+                if (desired || extra_done >= 3 || it == p.max_iter) break;
                 extra_done++;
             } else if (exhausted) {
                 status = HMPC_OPTIMAL;
@@ -1940,7 +1946,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                     block_reduce<D, 2>(v, op, S.red, lane);
                     pinf = v[0] / HMPC_RHO_OF(level); pmove = v[1];
                 }
-                if (!((al >= 1 && pinf <= 1e-12 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-13) || al == HMPC_POLISH_ITERS - 1)) {
+                // (the second level gets twice the steps: it is there for the slow sets)
+                if (!((al >= 1 && pinf <= 1e-12 * (1 + winf / tau) && HMPC_POLISH_DELTA * pmove <= 1e-13) || al == (level == 1 ? 2 * HMPC_POLISH_ITERS : HMPC_POLISH_ITERS) - 1)) {
                     al++;
                     mode = 2;
                     outcome = 2;
