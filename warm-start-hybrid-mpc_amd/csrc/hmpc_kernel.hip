@@ -798,7 +798,9 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
 // mreg x nz matrix the host keeps for the static row map (L2 resident, the same for every node), D from the
 // row vector in LDS, P_{t+1} from the LDS block the previous stage's elimination left it in.  The waves of the
 // node share the tiles; the lower triangle is computed and mirrored.  The list walk it replaces spent its time
-// on dependent global loads (index, then value) -- 70 k cycles per stage against ~3 k here.
+// on dependent global loads (index, then value) -- 70 k cycles per stage against ~20 k here.  Operands are read from
+// clamped indices and zeroed afterwards where a tile overhangs the matrix: a read under a lane predicate sits in a branch
+// of its own and waits for itself, which cost a quarter of this function's time.
 // ---------------------------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
@@ -811,10 +813,10 @@ template <class FA, class FB> DEV mfma_d4 mfma_tile(int wl, int K, FA a, FB b, m
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
     }
-    for (; k0 < K; k0 += 4) {
-        const int k = k0 + kq;
-        const double av = k < K ? a(r, k) : 0.0, bv = k < K ? b(k, r) : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    for (; k0 < K; k0 += 4) { // (reads from a clamped index, zeroed afterwards: a read under a lane predicate waits for itself)
+        const int k = k0 + kq, kc = k < K ? k : K - 1;
+        const double a0 = a(r, kc), b0 = b(kc, r);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(k < K ? a0 : 0.0, k < K ? b0 : 0.0, acc, 0, 0, 0);
     }
     return acc;
 }
@@ -830,8 +832,8 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
         const int ti = q / tn, tj = q - ti * tn;
         mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
         acc = mfma_tile(wl, nx,
-                        [&](int r, int k) { const int i = ti * 16 + r; return i < nx ? Pn[i * pns + k] : 0.0; },
-                        [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.AB[k * nz + j] : 0.0; }, acc);
+                        [&](int r, int k) { const int i = ti * 16 + r; const double v = Pn[(i < nx ? i : nx - 1) * pns + k]; return i < nx ? v : 0.0; },
+                        [&](int k, int c) { const int j = tj * 16 + c; const double v = S.AB[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         const int j = tj * 16 + (wl & 15);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -850,21 +852,21 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
         mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
         if (S.Cd)
             acc = mfma_tile(wl, p.mreg,
-                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? S.Cd[k * nz + i] * Dt[k] : 0.0; },
-                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.Cd[k * nz + j] : 0.0; }, acc);
+                            [&](int r, int k) { const int i = ti * 16 + r; const double v = S.Cd[k * nz + (i < nz ? i : nz - 1)] * Dt[k]; return i < nz ? v : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; const double v = S.Cd[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         else
             acc = mfma_tile(wl, p.mreg,
-                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? p.Creg[(size_t)k * nz + i] * Dt[k] : 0.0; },
-                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? p.Creg[(size_t)k * nz + j] : 0.0; }, acc);
+                            [&](int r, int k) { const int i = ti * 16 + r; const double v = p.Creg[(size_t)k * nz + (i < nz ? i : nz - 1)] * Dt[k]; return i < nz ? v : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; const double v = p.Creg[(size_t)k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         if (term) {
             const ldsd *De = S.e + p.Toff;
             acc = mfma_tile(wl, p.nT,
-                            [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? p.Ct[(size_t)k * nz + i] * De[k] : 0.0; },
-                            [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? p.Ct[(size_t)k * nz + j] : 0.0; }, acc);
+                            [&](int r, int k) { const int i = ti * 16 + r; const double v = p.Ct[(size_t)k * nz + (i < nz ? i : nz - 1)] * De[k]; return i < nz ? v : 0.0; },
+                            [&](int k, int c) { const int j = tj * 16 + c; const double v = p.Ct[(size_t)k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         }
         acc = mfma_tile(wl, nx,
-                        [&](int r, int k) { const int i = ti * 16 + r; return i < nz ? S.AB[k * nz + i] : 0.0; },
-                        [&](int k, int c) { const int j = tj * 16 + c; return j < nz ? S.PA[k * nz + j] : 0.0; }, acc);
+                        [&](int r, int k) { const int i = ti * 16 + r; const double v = S.AB[k * nz + (i < nz ? i : nz - 1)]; return i < nz ? v : 0.0; },
+                        [&](int k, int c) { const int j = tj * 16 + c; const double v = S.PA[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         const int j = tj * 16 + (wl & 15);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
