@@ -48,6 +48,7 @@ extern "C" {
 #define HMPC_UNBOUNDED 4 /* hmpc_lp_solve_batch only: the cost grows without bound on the set */
 
 #define HMPC_ITERS_POLISHED 0x10000 /* flag in hmpc_result.iters */
+#define HMPC_ITERS_WEAK 0x20000     /* flag in hmpc_result.iters: HMPC_INFEASIBLE, but the ray is no proof to tolerance */
 
 /* return codes */
 #define HMPC_OK 0
@@ -102,7 +103,12 @@ typedef struct hmpc_result {
     int32_t *status;  /* B                                                                    */
     int32_t *iters;   /* B : interior-point iterations spent on the node (low 16 bits);       */
                       /*     bit 16 (HMPC_ITERS_POLISHED): the record is the polished vertex    */
-                      /*     solution (exactly complementary), not the interior-point iterate   */
+                      /*     solution (exactly complementary), not the interior-point iterate;  */
+                      /*     bit 17 (HMPC_ITERS_WEAK): infeasible by about the accuracy of the  */
+                      /*     arithmetic -- the embedding's tau collapsed, the node has no point */
+                      /*     feasible to tolerance and is pruned, but its ray misses the proof  */
+                      /*     tolerance (tol_inf): it must not be carried to the next MPC step   */
+                      /*     (hmpc_fleet_* and the Python drivers reopen such a leaf at a shift) */
     double *primal;   /* B x n_primal                                                         */
     double *dual;     /* B x n_dual                                                           */
 } hmpc_result;

@@ -87,4 +87,6 @@ class OracleBatchedQP(object):
         if rc != 0:
             raise RuntimeError('oracle_solve_batch failed with code %d' % rc)
         out['time'] = time.perf_counter() - tic
+        out['weak'] = (out['polished'] >> 8) & 1        # infeasible, but the ray is no proof to tolerance (HMPC_ITERS_WEAK)
+        out['polished'] &= 0xff
         return out

@@ -33,14 +33,14 @@ def test_fleet_replays_the_published_runs():
     ref = load_fixture('reference_closed_loop')
     ctrl = make_controller('cart_pole_with_walls', backend='hip')
     for tag in ('0001', '0003'):
-        st = FleetMPC(ctrl, 12).closed_loop(X0, 50, ref['errors_' + tag], frontier_width=1)
+        st = FleetMPC(ctrl, 12).closed_loop(X0, 50, ref['errors_' + tag][:12], frontier_width=1)
         assert st['steps'] == 600
-        assert np.array_equal(st['len_ws'], ref['nodes_len_ws_' + tag])                        # published cover sizes, every step
-        ws, pws = st['nodes_ws'][:, 1:], ref['nodes_ws_' + tag][:, 1:]
+        assert np.array_equal(st['len_ws'], ref['nodes_len_ws_' + tag][:12])                      # published cover sizes, every step
+        ws, pws = st['nodes_ws'][:, 1:], ref['nodes_ws_' + tag][:12, 1:]
         calm = st['len_ws'][:, :-1] == 77
         assert np.median(ws[calm] - st['reopened'][:, :-1][calm]) == 9                         # dive + lost proofs (test_reference_replay.py)
         assert ws.mean() <= pws.mean() and ws.mean() >= 8.0
-        assert abs(st['nodes_ws'][:, 0].mean() - ref['nodes_cs_' + tag][:, 0].mean()) <= 3    # step 0 is a cold start
+        assert abs(st['nodes_ws'][:, 0].mean() - ref['nodes_cs_' + tag][:12, 0].mean()) <= 3    # step 0 is a cold start
 
 
 def test_speculative_expansion_in_the_fleet_changes_launches_not_results():

@@ -604,7 +604,9 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     const DevProb &p = h->dp;
     int rc = ensure_staging(h, B);
     if (rc) return rc;
-    const StageLayout L = stage_layout(p, (size_t)h->staged);
+    // offsets of THIS batch (they always fit the capacity the blocks were allocated for): with the capacity's offsets
+    // a small branch-and-bound round after one large call dragged the whole capacity-sized primal region along
+    const StageLayout L = stage_layout(p, (size_t)B);
     char *hs = (char *)h->h_stage, *ds = (char *)h->d_x0;
     const size_t nfix = (size_t)p.T * p.nub;
     if (x0_stride == 0) std::memcpy(hs + L.x0, x0, p.nx * sizeof(double));

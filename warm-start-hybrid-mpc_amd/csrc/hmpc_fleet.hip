@@ -58,7 +58,7 @@ struct hmpc_fleet {
     size_t cap_b = 0;
     int8_t *d_fix = nullptr, *h_fix = nullptr, *d_fix_out = nullptr;
     double *d_x0 = nullptr, *h_x0 = nullptr, *d_obj = nullptr, *h_obj = nullptr, *d_primal = nullptr, *h_nu = nullptr;
-    int32_t *d_status = nullptr, *h_status = nullptr, *d_iters = nullptr;
+    int32_t *d_status = nullptr, *h_status = nullptr, *d_iters = nullptr, *h_iters = nullptr;
     int32_t *d_owner = nullptr, *h_owner = nullptr, *d_src = nullptr, *h_src = nullptr;
     double *d_lb = nullptr, *h_lb = nullptr, *d_lb_out = nullptr;
     uint8_t *d_flags = nullptr, *h_flags = nullptr;
@@ -77,12 +77,12 @@ void fleet_free_round(hmpc_fleet *f)
     for (void *d : {(void *)f->d_fix, (void *)f->d_fix_out, (void *)f->d_x0, (void *)f->d_obj, (void *)f->d_primal, (void *)f->d_status, (void *)f->d_iters,
                     (void *)f->d_owner, (void *)f->d_src, (void *)f->d_lb, (void *)f->d_lb_out, (void *)f->d_flags})
         if (d) (void)hipFree(d);
-    for (void *d : {(void *)f->h_fix, (void *)f->h_x0, (void *)f->h_obj, (void *)f->h_nu, (void *)f->h_status, (void *)f->h_owner, (void *)f->h_src,
-                    (void *)f->h_lb, (void *)f->h_flags})
+    for (void *d : {(void *)f->h_fix, (void *)f->h_x0, (void *)f->h_obj, (void *)f->h_nu, (void *)f->h_status, (void *)f->h_iters, (void *)f->h_owner,
+                    (void *)f->h_src, (void *)f->h_lb, (void *)f->h_flags})
         if (d) (void)hipHostFree(d);
     f->d_fix = f->h_fix = f->d_fix_out = nullptr;
     f->d_x0 = f->h_x0 = f->d_obj = f->h_obj = f->d_primal = f->h_nu = nullptr;
-    f->d_status = f->h_status = f->d_iters = nullptr;
+    f->d_status = f->h_status = f->d_iters = f->h_iters = nullptr;
     f->d_owner = f->h_owner = f->d_src = f->h_src = nullptr;
     f->d_lb = f->h_lb = f->d_lb_out = nullptr;
     f->d_flags = f->h_flags = nullptr;
@@ -101,7 +101,7 @@ int fleet_ensure_round(hmpc_fleet *f, size_t B)
     bad |= dev_alloc(&f->d_x0, cap * p.nx) | pin_alloc(&f->h_x0, cap * p.nx);
     bad |= dev_alloc(&f->d_obj, cap) | pin_alloc(&f->h_obj, cap);
     bad |= pin_alloc(&f->h_nu, cap * 2 * nfix);
-    bad |= dev_alloc(&f->d_status, cap) | pin_alloc(&f->h_status, cap) | dev_alloc(&f->d_iters, cap);
+    bad |= dev_alloc(&f->d_status, cap) | pin_alloc(&f->h_status, cap) | dev_alloc(&f->d_iters, cap) | pin_alloc(&f->h_iters, cap);
     bad |= dev_alloc(&f->d_owner, cap) | pin_alloc(&f->h_owner, cap) | dev_alloc(&f->d_src, cap) | pin_alloc(&f->h_src, cap);
     bad |= dev_alloc(&f->d_lb, cap) | pin_alloc(&f->h_lb, cap) | dev_alloc(&f->d_lb_out, cap);
     bad |= dev_alloc(&f->d_flags, cap) | pin_alloc(&f->h_flags, cap);
@@ -303,6 +303,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             if ((rc = hmpc_solve_batch_device(h, f->d_x0, nx, f->d_fix, (int32_t)B, &r, f->stream))) return rc;
             HIPCHK(hipMemcpyAsync(f->h_obj, f->d_obj, B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpyAsync(f->h_status, f->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipMemcpyAsync(f->h_iters, f->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpy2DAsync(f->h_nu, 2 * nfix * sizeof(double), rows + o_lb, p.n_dual * sizeof(double), 2 * nfix * sizeof(double), B,
                                     hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipStreamSynchronize(f->stream));
@@ -310,6 +311,12 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             f->launched += (long long)B;
             for (size_t q = 0; q < B; q++) {
                 if (f->h_status[q] > 1) return fail(HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
+                if (f->h_iters[q] & HMPC_ITERS_WEAK) {
+                    // infeasible, but the ray is no proof to tolerance: it prunes this node at this step only.  With a
+                    // dual objective of -inf the shift reopens the leaf whatever the model error (controller.py:555-558).
+                    const double ninf = -inf;
+                    HIPCHK(hipMemcpy(f->dobj[f->cur] + f->used + q, &ninf, sizeof(double), hipMemcpyHostToDevice));
+                }
                 const int d = launch[q].depth;
                 const double *nu_ = f->h_nu + q * 2 * nfix;
                 FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q)};

@@ -1644,7 +1644,7 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 // Returns status; tau and the iteration count through references.
 template <class D, int RS, class RM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  bool &polished_out, double *trace)
+                  bool &polished_out, bool &weak_out, double *trace)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -1670,6 +1670,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
     polished_out = false;
+    weak_out = false;
     bool tried = false; // the polish has been tried (and failed) on the current iterate
     int attempts = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
@@ -1831,6 +1832,17 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         // not prune a subtree (a node whose tau vanishes without one ends MAXITER / NUMERICAL and is surfaced).
         if (!polish && eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
             status = HMPC_INFEASIBLE;
+            break;
+        }
+        // tau has collapsed but the ray is no proof to tolerance: the node is infeasible by about the accuracy of the
+        // linear algebra (its least-violated point misses the rows by ~1e-6; met on the published sd = 0.01 runs).  The
+        // embedding's conclusion (tau -> 0 with kappa > 0 and a cost bounded below: no feasible point) is taken -- the
+        // node is pruned, as by a simplex code with a 1e-6 feasibility tolerance -- but the ray is flagged WEAK
+        // (HMPC_ITERS_WEAK): it prunes this node only, the warm-start shift never carries it to the next step.
+        // Same rule as oracle/hsde_qp.c.
+        if (!polish && eta > 0 && tau <= 1e-8 * kap && certinf <= 0.5 * eta) {
+            status = HMPC_INFEASIBLE;
+            weak_out = true;
             break;
         }
         if (!polish && it == p.max_iter) break;
@@ -2460,7 +2472,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
 #endif
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
-        bool polished = false;
+        bool polished = false, weak = false;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
         // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
@@ -2470,7 +2482,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, tr ? tr + term_on * 64 * 8 : nullptr);
+            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, weak, tr ? tr + term_on * 64 * 8 : nullptr);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -2495,7 +2507,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
         HMPC_CHK(status >= HMPC_OPTIMAL && status <= HMPC_NUMERICAL && tau > 0.0, 7);
 #endif
-        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0);
+        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0);
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
         slot = S.flag[1];

@@ -165,7 +165,9 @@ class BatchedMPC(object):
         tr.lb[node] = obj
         tr.solved[node] = True
         tr.dual[node] = res['dual'][b]
-        tr.dobj[node] = res['dual_obj'][b]
+        # an infeasibility ray that is no proof to tolerance (HMPC_ITERS_WEAK) prunes its node at this step only: with a
+        # dual objective of -inf the shift reopens the leaf whatever the model error (controller.py:555-558)
+        tr.dobj[node] = -np.inf if res['weak'][b] else res['dual_obj'][b]
         tr.has_dual[node] = True
         cutoff = tr.ub - tol
         if obj >= cutoff:

@@ -193,8 +193,10 @@ class HybridModelPredictiveController(object):
             # MAXITER / NUMERICAL nodes are surfaced, never silently treated as solved
             raise RuntimeError('QP solver did not converge on %d of %d nodes (status %s, first node %d)'
                                % (bad.size, fix.shape[0], sorted(set(res['status'][bad].tolist())), bad[0]))
+        weak = res.get('weak')
         sols = [SubproblemSolution.from_rows(self.layout, fix[b], res['obj'][b], res['dual_obj'][b],
-                                             res['status'][b], res['primal'][b], res['dual'][b])
+                                             res['status'][b], res['primal'][b], res['dual'][b],
+                                             weak=weak is not None and weak[b])
                 for b in range(fix.shape[0])]
         return sols, res['time']
 
@@ -324,6 +326,8 @@ class HybridModelPredictiveController(object):
             old = leaf.extra.dual.variables
             new = self._shift_dual_variables(old)
             objective = leaf.extra.dual.objective + self._pi_sum(leaf.identifier, old, new, x0, u0)
+            if getattr(leaf.extra.dual, 'weak', False):
+                objective = -np.inf        # a ray that is no proof to tolerance is not carried over: the leaf reopens below
             warm_start.append(Node(shifted_identifier, leaf.lb, SubproblemSolution(None, DualSolution(new, objective))))
         toc = time() - tic
         gc.enable()

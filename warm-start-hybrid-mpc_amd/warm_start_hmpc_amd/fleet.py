@@ -87,3 +87,62 @@ class FleetMPC(object):
         wall = perf_counter() - tic
         st.update(wall=wall, steps=steps, steps_per_sec=steps / wall if wall > 0 else 0.)
         return st
+
+
+def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, speculation=0, log=None, sim_ids=None):
+    """The reference's closed-loop study (``notebooks/cart_pole_with_walls/statistical_analysis.py:93-196``) on the fleet
+    driver: K simulations in lockstep under prescribed model errors ``errors`` (K, n_steps, nx); at every step a
+    cold-started search (a second fleet, reset before every step; ``cold_too``) and a warm-started one from the same
+    state, their costs compared (the reference's assertion at :171; a disagreement is recorded, not raised), the next
+    warm start built from the warm search's leaves (:180-187).  A simulation ends at the step whose MIQP has no solution
+    (:165-166).  ``frontier_width=1`` is the reference's node order.
+
+    Returns the dictionary of ``BatchedMPC.closed_loop``: per simulation the lists nodes_cs, nodes_ws, len_ws, reopened,
+    costs (one entry per step the simulation was alive for; len_ws / reopened / costs only for steps with a solution),
+    cost_mismatches [(simulation, step, cold cost, warm cost)], wall, steps, steps_per_sec, survivors.
+    """
+    errors = np.asarray(errors, dtype=np.float64)
+    K, n_steps = errors.shape[:2]
+    sim_ids = list(range(K)) if sim_ids is None else list(sim_ids)
+    warm = FleetMPC(controller, K)
+    cold = FleetMPC(controller, K) if cold_too else None
+    xs = np.repeat(np.asarray(x0, dtype=np.float64)[None], K, axis=0)
+    alive = np.ones(K, dtype=bool)
+    st = dict(nodes_ws=[[] for _ in range(K)], nodes_cs=[[] for _ in range(K)], len_ws=[[] for _ in range(K)],
+              costs=[[] for _ in range(K)], reopened=[[] for _ in range(K)], cost_mismatches=[])
+    steps = 0
+    tic = perf_counter()
+    for t in range(n_steps):
+        if not alive.any():
+            break
+        rc = None
+        if cold is not None:
+            for k in np.flatnonzero(alive):             # (an ended simulation is not reset: it stays ended)
+                cold.reset(int(k))
+            rc = cold.solve(xs, frontier_width, speculation=speculation)
+        rw = warm.solve(xs, frontier_width, speculation=speculation)
+        ok = alive & np.isfinite(rw['cost'])
+        cover, reopened = warm.shift(errors[:, t])
+        for k in np.flatnonzero(alive):
+            st['nodes_ws'][k].append(int(rw['solves'][k]))
+            if rc is not None:
+                st['nodes_cs'][k].append(int(rc['solves'][k]))
+                if not (np.isclose(rw['cost'][k], rc['cost'][k], rtol=1e-5, atol=1e-8) or
+                        (np.isinf(rw['cost'][k]) and np.isinf(rc['cost'][k]))):
+                    st['cost_mismatches'].append((sim_ids[k], t, float(rc['cost'][k]), float(rw['cost'][k])))
+            if ok[k]:
+                st['len_ws'][k].append(int(cover[k]))
+                st['reopened'][k].append(int(reopened[k]))
+                st['costs'][k].append(float(rw['cost'][k]))
+                if log is not None:
+                    cs = '(cs: %d) ' % rc['solves'][k] if rc is not None else ''
+                    log.write('sim %d Time step %d %s(ws: %d) (ws info: %d) (e: %.3f, %s)\n'
+                              % (sim_ids[k], t, cs, rw['solves'][k], cover[k], np.linalg.norm(errors[k, t]), errors[k, t]))
+        xs = np.where(ok[:, None], rw['x1'] + errors[:, t], xs)
+        steps += int(ok.sum())
+        alive = ok
+    wall = perf_counter() - tic
+    st.update(wall=wall, steps=steps, steps_per_sec=steps / wall if wall > 0 else 0., survivors=int(alive.sum()),
+              rounds=warm.stats()['rounds'] + (cold.stats()['rounds'] if cold else 0),
+              launched=warm.stats()['launched'] + (cold.stats()['launched'] if cold else 0))
+    return st

@@ -2,7 +2,10 @@
 ``notebooks/cart_pole_with_walls/statistical_analysis.py`` (same initial state, horizon, error model
 ``e_t = sd * randn(nx) * x_max`` drawn from ``np.random.seed(simulation index)``, one cold-started and
 one warm-started branch and bound per step, equal-cost assertion), with all simulations advanced in
-lockstep so that their branch-and-bound rounds share kernel launches.
+lockstep so that their branch-and-bound rounds share kernel launches.  On the GPU the study runs on the C++ fleet
+driver behind the C ABI (``fleet.closed_loop_study`` over ``hmpc_fleet_*``: trees behind the handle, multiplier rows
+resident in HBM); ``--errors FILE.npz --errors-key KEY`` replays prescribed disturbances instead of drawing them (the
+reference's published ones: tests/golden/reference_closed_loop.npz, keys errors_0001 / errors_0003 / errors_0010).
 
     python -m warm_start_hmpc_amd.monte_carlo --fixture tests/golden/cart_pole_with_walls.npz \
         --sims 100 --steps 50 --sd 0.003 --out gpurun_out/mc
@@ -36,6 +39,8 @@ def main(argv=None, backend_factory=None):
     ap.add_argument('--width', type=int, default=8)
     ap.add_argument('--no-cold', action='store_true')
     ap.add_argument('--out', default='.')
+    ap.add_argument('--errors', default=None, help='.npz with prescribed model errors (sims, steps, nx)')
+    ap.add_argument('--errors-key', default='errors')
     args = ap.parse_args(argv)
 
     from .mld_system import MLDSystem
@@ -60,20 +65,31 @@ def main(argv=None, backend_factory=None):
             pass
         ctrl = HybridModelPredictiveController(mld, data['T'], data['objective'], data['terminal_set'], backend=_Late())
         ctrl.qp = backend_factory(ctrl.problem_data())
-    bm = BatchedMPC(ctrl)
     os.makedirs(args.out, exist_ok=True)
     tag = 'sd_{:.3f}'.format(args.sd)
     seeds = tuple(range(rank, args.sims, world))           # this rank's simulations
+    # the disturbance of simulation i at step t: e_sd * randn(nx) * x_max from the stream of np.random.seed(i)
+    # (statistical_analysis.py:73,176), or the prescribed one
+    if args.errors is not None:
+        errors = np.load(args.errors)[args.errors_key][list(seeds), :args.steps]
+    else:
+        errors = np.array([[args.sd * np.multiply(rng.randn(mld.nx), d['x_max']) for _ in range(args.steps)]
+                           for rng in (np.random.RandomState(s) for s in seeds)]).reshape(len(seeds), args.steps, mld.nx)
+    x0 = np.array([0., 0., 1., 0.])
     log_name = 'solve_log_%s.log' % tag if world == 1 else 'solve_log_%s.rank%d.log' % (tag, rank)
     with open(os.path.join(args.out, log_name), 'w') as log:
         log.write('Error standard deviation {:.3f}\n\n'.format(args.sd))
-        st = bm.closed_loop(np.array([0., 0., 1., 0.]), args.steps, e_sd=args.sd, seeds=seeds,
-                            x_max=d['x_max'], frontier_width=args.width, cold_too=not args.no_cold, log=log)
+        if backend_factory is None:                        # the product path: the fleet driver behind the C ABI
+            from .fleet import closed_loop_study
+            st = closed_loop_study(ctrl, x0, errors, frontier_width=args.width, cold_too=not args.no_cold, log=log, sim_ids=seeds)
+        else:
+            st = BatchedMPC(ctrl).closed_loop(x0, args.steps, seeds=seeds, frontier_width=args.width, cold_too=not args.no_cold,
+                                              log=log, errors=errors)
     if world > 1:
         # per-simulation lists back into global simulation order; counters summed; wall = slowest rank
         parts = [None] * world
-        dist.all_gather_object(parts, {k: st[k] for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'costs', 'cost_mismatches', 'steps', 'wall')})
-        merged = {k: [None] * args.sims for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'costs')}
+        dist.all_gather_object(parts, {k: st[k] for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'reopened', 'costs', 'cost_mismatches', 'steps', 'wall')})
+        merged = {k: [None] * args.sims for k in ('nodes_ws', 'nodes_cs', 'len_ws', 'reopened', 'costs')}
         for r, part in enumerate(parts):
             for j, sim in enumerate(range(r, args.sims, world)):
                 for k in merged:
@@ -84,7 +100,7 @@ def main(argv=None, backend_factory=None):
         if rank != 0:
             return 0
     full = [k for k in range(args.sims) if len(st['nodes_ws'][k]) == args.steps and len(st['costs'][k]) == args.steps]
-    for key in ('nodes_ws', 'nodes_cs', 'len_ws'):
+    for key in ('nodes_ws', 'nodes_cs', 'len_ws', 'reopened'):
         rows = [st[key][k] for k in full if len(st[key][k]) == args.steps]
         if rows:
             np.save(os.path.join(args.out, '%s_%s.npy' % (key, tag)), np.array(rows))
@@ -97,6 +113,10 @@ def main(argv=None, backend_factory=None):
             print('cold solves/step: mean %.2f min %d max %d' % (cs.mean(), cs.min(), cs.max()))
         lw = np.array([st['len_ws'][k] for k in full])
         print('cover size: min %d max %d' % (lw.min(), lw.max()))
+        print('infeasibility proofs lost per shift: mean %.2f' % np.mean([st['reopened'][k] for k in full]))
+    ended = [(k, len(st['costs'][k])) for k in range(args.sims) if k not in full]
+    if ended:
+        print('simulations that left the feasible set (simulation, step): %s' % ended)
     print('warm/cold cost disagreements (np.isclose rtol 1e-5): %d of %d steps %s'
           % (len(st['cost_mismatches']), st['steps'], st['cost_mismatches'][:3]))
     print('wall %.2f s, %.1f MPC steps/s (all simulations)' % (st['wall'], st['steps_per_sec']))

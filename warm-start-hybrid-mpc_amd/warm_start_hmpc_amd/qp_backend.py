@@ -235,6 +235,7 @@ class HipBatchedQP(object):
         self._check(self.lib.hmpc_solve_batch(self.handle, x0.ctypes.data, stride, fix.ctypes.data, B, ctypes.byref(res)))
         out['time'] = time.perf_counter() - tic
         out['polished'] = (out['iters'] >> 16) & 1      # HMPC_ITERS_POLISHED
+        out['weak'] = (out['iters'] >> 17) & 1          # HMPC_ITERS_WEAK: infeasible, the ray is no proof to tolerance
         out['iters'] = out['iters'] & 0xFFFF
         return out
 

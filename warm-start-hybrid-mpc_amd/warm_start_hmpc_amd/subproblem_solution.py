@@ -16,6 +16,7 @@ class SubproblemSolution(object):
         self._primal = primal
         self._dual = dual
         self._rows = None
+        self.weak = False
         # the reference hands a simplex basis from parent to child when Gurobi
         # runs its dual simplex (subproblem_solution.py:38-43); the batched
         # interior-point kernels have no basis, the slot stays None
@@ -28,6 +29,7 @@ class SubproblemSolution(object):
         self._rows = None
         self._primal = PrimalSolution.from_row(layout, fix_row, obj, primal_row, not np.isfinite(obj))
         self._dual = DualSolution.from_row(layout, dual_obj, dual_row)
+        self._dual.weak = self.weak
 
     @property
     def primal(self):
@@ -61,11 +63,13 @@ class SubproblemSolution(object):
         return self._primal.objective, self._primal.binary_feasible
 
     @staticmethod
-    def from_rows(layout, fix_row, obj, dual_obj, status, primal_row, dual_row):
-        """Record of one node from one row of a batch result (the rows are kept by reference)."""
+    def from_rows(layout, fix_row, obj, dual_obj, status, primal_row, dual_row, weak=False):
+        """Record of one node from one row of a batch result (the rows are kept by reference).
+        ``weak``: the node is infeasible but its ray is no proof to tolerance (HMPC_ITERS_WEAK, include/hmpc.h)."""
         sol = SubproblemSolution(None, None)
         sol._rows = (layout, fix_row, obj, dual_obj, primal_row, dual_row)
         sol.status = int(status)
+        sol.weak = bool(weak)
         return sol
 
 
@@ -108,6 +112,9 @@ class DualSolution(object):
     def __init__(self, variables, objective):
         self.variables = variables
         self.objective = objective
+        # an infeasibility ray that misses the proof tolerance (the node is infeasible by about the accuracy of the
+        # arithmetic): it prunes its node, but the warm-start shift does not carry it to the next step
+        self.weak = False
 
     @staticmethod
     def from_row(layout, dual_obj, row):
