@@ -23,12 +23,57 @@ X0 = np.array([0., 0., 1., 0.])
 RTOL = 1e-5   # north_star: continuous trajectories within 1e-5 relative -- ONE tolerance, every node, every config
 
 
+ETOL, EFLOOR = 1e-5, 1e-6   # element-wise: every component within 1e-5 of its own size (components below 1e-6: of 1e-6)
+WORST = {'norm': 0.0, 'element': 0.0, 'dense': 0.0}   # largest deviations seen in this session (printed at the end)
+
+
 def _rel(a, b):
-    """Largest deviation of a from b per row, relative to the row's largest entry of b (floor 1e-2)."""
-    if a.shape[1] == 0:
+    """Largest deviation of a from b per row, relative to the row's largest entry of b (floor 1e-2) -- and, beside
+    that norm-wise measure, the element-wise one: every component relative to its OWN size (floor EFLOOR), so that a
+    small component (a pole angle of 1e-3 next to a velocity of 1) is held to the same relative accuracy."""
+    if a.shape[1] == 0 or a.shape[0] == 0:
         return np.zeros(a.shape[0])
     scale = np.maximum(1e-2, np.max(np.abs(b), axis=1, keepdims=True))
-    return np.max(np.abs(a - b) / scale, axis=1)
+    norm = np.max(np.abs(a - b) / scale, axis=1)
+    elem = np.max(np.abs(a - b) / np.maximum(np.abs(b), EFLOOR), axis=1)
+    WORST['norm'], WORST['element'] = max(WORST['norm'], norm.max()), max(WORST['element'], elem.max())
+    return np.maximum(norm, elem * (RTOL / ETOL))
+
+
+_DENSE = {}
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _report_worst_deviations():
+    yield
+    line = ('parity margins of this run: kernel vs oracle norm-wise %.2e, element-wise (floor %.0e) %.2e; kernel vs dense '
+            'active-set solve %.2e' % (WORST['norm'], EFLOOR, WORST['element'], WORST['dense']))
+    print('\n' + line)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'parity_margins.txt'), 'a') as f:
+            f.write(line + '\n')
+
+
+def _dense_check(ctrl, T, x0, fix, rec, sample=64, seed=0):
+    """The kernel's optimal records against the dense active-set solve (tests/dense_qp.py: numpy SVD on the dense
+    statement of the node QP, no code shared with oracle or kernel) -- a seeded sample per call, states to 1e-7."""
+    from dense_qp import dense_qp, active_set_primal
+    key = id(ctrl)
+    if key not in _DENSE:
+        _DENSE[key] = dense_qp(ctrl)
+    opt = np.flatnonzero((rec['status'] == 0) & (rec['polished'] > 0))
+    if opt.size > sample:
+        opt = np.random.RandomState(seed).choice(opt, sample, replace=False)
+    nxs = (T + 1) * ctrl.mld.nx
+    x0 = np.asarray(x0)
+    for i in opt:
+        w, resid = active_set_primal(ctrl, _DENSE[key], x0 if x0.ndim == 1 else x0[i], np.asarray(fix)[i], rec['dual'][i])
+        assert resid < 1e-9, resid
+        dev = np.max(np.abs(w[:nxs] - rec['primal'][i][:nxs])) / max(1e-2, np.max(np.abs(w[:nxs])))
+        WORST['dense'] = max(WORST['dense'], dev)
+        assert dev < 1e-7, ('dense active-set solve', int(i), dev)
+    return opt.size
 
 
 def _trajectories_close(ctrl, T, fix, pa, pb, what=''):
@@ -47,8 +92,12 @@ def _trajectories_close(ctrl, T, fix, pa, pb, what=''):
             assert _rel(ua[full].reshape(full.sum(), -1), ub[full].reshape(full.sum(), -1)).max() < RTOL, (what, 'u of fully fixed nodes')
 
 
-def _compare(ctrl, a, b, T, fix=None, min_polished=1.0):
+def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
+    """a: records of the HIP path, b: of the oracle.  With x0 (and fix) the polished records of the HIP path are also
+    checked against the dense active-set solve, which shares no code with either."""
     assert np.array_equal(a['status'], b['status']), np.flatnonzero(a['status'] != b['status'])
+    if x0 is not None and fix is not None:
+        _dense_check(ctrl, T, x0, fix, a)
     assert np.all(a['status'] <= 1)
     fin = a['status'] == 0
     # polished on both sides (every optimal node of the cart-pole systems): vertex solutions, objectives to 1e-8;
@@ -84,7 +133,7 @@ def test_frontier_parity_with_oracle(fixture, T, terminal, count, p_one):
     fix = random_prefix_frontier(T, hip.mld.nub, count, p_one=p_one)
     fix[0, :] = -1
     x0 = np.array([0., 0., .5, 0.]) if T == 10 and terminal else X0
-    _compare(hip, hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix), T, fix)
+    _compare(hip, hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix), T, fix, x0=x0)
 
 
 @pytest.mark.parametrize('waves', ['1', '2', '4'])
@@ -99,7 +148,7 @@ def test_every_kernel_instantiation(monkeypatch, fixture, T, waves):
     monkeypatch.setenv('HMPC_WAVES', waves)
     res = hip.qp.solve_batch(X0, fix)
     monkeypatch.delenv('HMPC_WAVES')
-    _compare(hip, res, orc.qp.solve_batch(X0, fix), T, fix)
+    _compare(hip, res, orc.qp.solve_batch(X0, fix), T, fix, x0=X0)
 
 
 def test_shallow_wide_family_polishes_everywhere():
@@ -112,7 +161,7 @@ def test_shallow_wide_family_polishes_everywhere():
     hip = make_controller('cart_pole_one_wall', T=40, backend='hip')
     orc = make_controller('cart_pole_one_wall', T=40, backend='oracle', threads=8)
     a, b = hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix)
-    _compare(hip, a, b, 40, fix)
+    _compare(hip, a, b, 40, fix, x0=x0)
     opt = np.flatnonzero(a['status'] == 0)
     assert opt.size > 300 and np.all(a['polished'][opt] > 0)
     dq = dense_qp(hip)
@@ -133,7 +182,7 @@ def test_generic_kernel_forced_on_cart_pole(monkeypatch):
     for count in (32, 600):                                  # 4 waves and 1 wave per node
         fix = random_prefix_frontier(20, 4, count, p_one=0.2, seed0=11000)
         fix[0, :] = -1
-        _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix)
+        _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix, x0=X0)
 
 
 def test_per_node_initial_states():
@@ -142,7 +191,7 @@ def test_per_node_initial_states():
     rng = np.random.default_rng(5)
     fix = random_prefix_frontier(10, 4, 96, p_one=0.05)
     x0 = rng.uniform(-1, 1, (96, 4)) * np.array([.3, .1, .6, .4])
-    _compare(hip, hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix), 10, fix)
+    _compare(hip, hip.qp.solve_batch(x0, fix), orc.qp.solve_batch(x0, fix), 10, fix, x0=x0)
 
 
 def test_golden_vectors():
@@ -341,7 +390,7 @@ def test_streaming_kernel_forced_on_cart_pole(monkeypatch):
     orc = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
     fix = random_prefix_frontier(20, 4, 96, p_one=0.2, seed0=7000)
     fix[0, :] = -1
-    _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix)
+    _compare(hip, hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix), 20, fix, x0=X0)
 
 
 def test_lockstep_closed_loops_on_gpu():
@@ -422,7 +471,7 @@ def test_replayed_real_frontier():
     fix = np.tile(nodes, (1024 // len(nodes) + 1, 1))[:1024]
     hip = make_controller('cart_pole_with_walls', backend='hip')
     a, b = hip.qp.solve_batch(X0, fix), orc.qp.solve_batch(X0, fix)
-    _compare(hip, a, b, 20, fix)
+    _compare(hip, a, b, 20, fix, x0=X0)
     feasible = (a['status'] == 0).mean()
     assert 0.3 < feasible < 0.7                                        # about half of a real tree's nodes are feasible
     # copies of the same node in different batch positions give the same bits

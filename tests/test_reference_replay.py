@@ -27,6 +27,12 @@ from helpers import make_controller, load_fixture
 from warm_start_hmpc_amd.batched import BatchedMPC
 
 X0 = np.array([0., 0., 1., 0.])
+# The ONE place in the 15 166 published steps where the published cover is not reproduced -- by oracle, kernel and fleet
+# driver alike: at step 11 of simulation 94 (sd 0.003) the MIQP has a TIE -- two assignments of the last stages' binaries
+# cost the same to 4e-10 relative (test_the_one_deviation_from_the_published_covers_is_a_tie below).  The dive meets the
+# one that is worse in the tenth digit first, so the subtree of the other is opened as well: 3 more solves, 2 more
+# leaves, carried for three steps until the shift drops them.  Gurobi met them in the other order (or saw them equal).
+KNOWN_TIES = {('0003', 94): {11: 175, 12: 175, 13: 175}}
 
 
 def _compare(st, tag, sims, steps, max_lost=1.0, warm_mean=True):
@@ -41,10 +47,17 @@ def _compare(st, tag, sims, steps, max_lost=1.0, warm_mean=True):
         n = min(int(pub_steps[j]), steps)                # steps with a solution (a warm start was built)
         lw, cs, ws = np.array(st['len_ws'][j]), np.array(st['nodes_cs'][j]), np.array(st['nodes_ws'][j])
         assert len(lw) == n, (tag, i, len(lw), n)                        # the simulation ends where the published one does
-        assert np.array_equal(lw, ref['nodes_len_ws_' + tag][i, :n]), (tag, i)   # cover sizes: exactly the published ones
+        want = ref['nodes_len_ws_' + tag][i, :n].copy()
+        tie = KNOWN_TIES.get((tag, i), {})
+        for t, v in tie.items():
+            if t < n:
+                want[t] = v
+        assert np.array_equal(lw, want), (tag, i)                        # cover sizes: exactly the published ones
         m = len(cs)                                                      # == n, or n + 1: the step that has no solution
         assert m == (n + 1 if n < min(steps, 50) else n), (tag, i, m, n)
-        assert np.max(np.abs(cs - ref['nodes_cs_' + tag][i, :m])) <= 3, (tag, i)  # cold solves, also on the infeasible step
+        dcs = np.abs(cs - ref['nodes_cs_' + tag][i, :m])
+        assert np.all(dcs[[t for t in range(m) if t not in tie]] <= 3), (tag, i)  # cold solves, also on the infeasible step
+        assert np.all(dcs <= 6)
         tot['cs'].append(cs[:n]); tot['pcs'].append(ref['nodes_cs_' + tag][i, :n])
         if n > 1:
             tot['ws'].append(ws[1:n]); tot['pws'].append(ref['nodes_ws_' + tag][i, 1:n])
@@ -83,6 +96,31 @@ def test_replay_of_the_published_large_disturbances_cpu():
     ctrl = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
     r = _replay(ctrl, '0010', sims=(0, 93, 81), steps=12, max_lost=6.0, warm_mean=False)
     assert r['cover_max'] == 149
+
+
+def test_the_one_deviation_from_the_published_covers_is_a_tie():
+    # simulation 94 of sd 0.003 up to step 11 (KNOWN_TIES): the cold search of that step meets a first incumbent and then
+    # a second, fully fixed node whose cost is lower by less than 1e-9 relative -- an exact tie of the MIQP to the
+    # accuracy of any solver; covers before it equal the published ones, the cover after it has the two extra leaves
+    ref = load_fixture('reference_closed_loop')
+    ctrl = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
+    bm = BatchedMPC(ctrl)
+    seen, marks, consume, many = [], [], bm._consume, bm.feedforward_many
+
+    def spy_consume(tr, node, res, b, tol):
+        seen.append((float(res['obj'][b]), int((tr.fix[node] >= 0).sum())))
+        return consume(tr, node, res, b, tol)
+
+    def spy_many(*a, **k):
+        marks.append(len(seen))
+        return many(*a, **k)
+    bm._consume, bm.feedforward_many = spy_consume, spy_many
+    st = bm.closed_loop(X0, 12, seeds=(94,), frontier_width=1, cold_too=True, errors=ref['errors_0003'][[94]])
+    assert st['len_ws'][0][:11] == ref['nodes_len_ws_0003'][94, :11].tolist()
+    assert st['len_ws'][0][11] == 175 and ref['nodes_len_ws_0003'][94, 11] == 173
+    cold = seen[marks[22]:marks[23]]                      # calls alternate cold, warm: step 11's cold search is call 22
+    full = sorted(o for o, depth in cold if depth == ctrl.T * ctrl.mld.nub and np.isfinite(o))
+    assert len(full) >= 2 and 0 < (full[1] - full[0]) / full[0] < 1e-9
 
 
 def test_without_the_lazy_terminal_set_every_proof_is_lost():
