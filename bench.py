@@ -2,12 +2,20 @@
 """bench.py -- QP subproblems/s of the batched B&B-node solver on MI355X.
 
 A "step" is one pass of the hot path over one synthetic frontier: every rank
-solves ``--frontier`` random-prefix nodes of the cart-pole-with-walls MIQP
-(N=20, 4 binaries/step; BASELINE.json configs[1], frontier generator of
-SURVEY.md 8(d) C2) with inputs already resident in HBM, then -- when more than
-one rank runs -- all ranks exchange the incumbent upper bound with one RCCL
-all-reduce(min) of 8 bytes.  Frontier nodes are independent, so ranks hold
-disjoint shards and the scaling is weak (fixed work per GPU).
+solves ``--frontier`` nodes of the cart-pole-with-walls MIQP (N=20, 4
+binaries/step; BASELINE.json configs[1]) with inputs already resident in HBM,
+then -- when more than one rank runs -- all ranks exchange the incumbent upper
+bound with one RCCL all-reduce(min) of 8 bytes.  Frontier nodes are independent,
+so ranks hold disjoint shards and the scaling is weak (fixed work per GPU).
+
+The default frontier (``--frontier-kind real_tree``, SURVEY.md 8(d) C2 "replay
+frontier") is what a branch and bound actually solves: every node that
+cold-started searches from perturbed initial states solve, plus their leaves --
+about a third of them optimal, the rest infeasible -- each node once, cold (no
+hand-down from its parent: every record is what a stand-alone solve returns).
+``--frontier-kind random_prefix`` is the random-binary generator of the same
+section (p = 0.5: 98 % infeasible, the easy mix; p = 0.1); both, the hand-down
+variant and the other configs are secondary keys of the default run.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frontier B]
 
@@ -99,8 +107,10 @@ def shift_bandwidth(ctrl, dev, leaves=65536, trees=64, reps=10):
             'kernel': 'hmpc_shift_kernel'}
 
 
-def _device_rate(qp, x0_h, fix_h, dev, reps=5, warm=2):
-    """QP/s of one frontier, inputs resident in HBM, HIP events on the launch stream; statuses and iteration counts."""
+def _device_rate(qp, x0_h, fix_h, dev, reps=5, warm=2, parent=None):
+    """QP/s of one frontier, inputs resident in HBM, HIP events on the launch stream; statuses and iteration counts.
+    parent (int32 [B], -1: none): every node is handed the record of its parent (hmpc_warm), taken from one untimed
+    cold pass over the same frontier."""
     import torch
     B = fix_h.shape[0]
     fix = torch.from_numpy(np.ascontiguousarray(fix_h)).to(dev)
@@ -109,59 +119,78 @@ def _device_rate(qp, x0_h, fix_h, dev, reps=5, warm=2):
                status=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
                primal=torch.empty(B, qp.n_primal, dtype=torch.float64, device=dev),
                dual=torch.empty(B, qp.n_dual, dtype=torch.float64, device=dev))
+    hand = None
+    if parent is not None:
+        par = dict(out, primal=torch.empty_like(out['primal']), dual=torch.empty_like(out['dual']))
+        qp.solve_batch_device(x0, fix, par)
+        torch.cuda.synchronize()
+        st, itf = par['status'].cpu().numpy(), par['iters'].cpu().numpy()
+        good = (parent >= 0) & (st[np.maximum(parent, 0)] == 0) & (((itf[np.maximum(parent, 0)] >> 16) & 1) > 0)
+        hand = (par['primal'], par['dual'], torch.from_numpy(np.where(good, parent, -1).astype(np.int32)).to(dev))
     for _ in range(warm):
-        qp.solve_batch_device(x0, fix, out)
+        qp.solve_batch_device(x0, fix, out, warm=hand)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
     for a, b in ev:
         a.record()
-        qp.solve_batch_device(x0, fix, out)
+        qp.solve_batch_device(x0, fix, out, warm=hand)
         b.record()
     torch.cuda.synchronize()
     ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     status = out['status'].cpu().numpy()
     raw = out['iters'].cpu().numpy()
     grid, lds = qp.launch_info()
-    return {'nodes': B, 'kernel_ms_avg': ms, 'qp_per_s': B / (ms * 1e-3), 'optimal': int((status == 0).sum()),
-            'infeasible': int((status == 1).sum()), 'not_converged': int((status > 1).sum()),
-            'polished': int(((raw >> 16) & 1).sum()), 'ipm_iters_mean': float((raw & 0xFFFF).mean()), 'grid': grid,
-            'lds_bytes_per_wg': lds}, status
+    r = {'nodes': B, 'kernel_ms_avg': ms, 'qp_per_s': B / (ms * 1e-3), 'optimal': int((status == 0).sum()),
+         'infeasible': int((status == 1).sum()), 'not_converged': int((status > 1).sum()),
+         'polished': int(((raw >> 16) & 1).sum()), 'ipm_iters_mean': float((raw & 0xFFFF).mean()),
+         'ipm_iters_mean_optimal': float((raw & 0xFFFF)[status == 0].mean()) if (status == 0).any() else None,
+         'grid': grid, 'lds_bytes_per_wg': lds}
+    if hand is not None:
+        r['handed_down'] = int((hand[2] >= 0).sum().item())
+        r['handed_down_verified'] = int(((raw >> 18) & 1).sum())
+    return r, status
 
 
-def secondary_frontiers(ctrl, dev, x0_h):
-    """The other frontiers of SURVEY 8(d) C2 on the headline system (the headline line is the p = 0.5 stress variant,
-    97.7 % infeasible): p = 0.1, the replayed real tree, the 1024-node size of BASELINE configs[2], and -- from one
-    large random frontier -- optimal and infeasible nodes apart."""
-    from helpers import random_prefix_frontier
+def secondary_frontiers(ctrl, dev, x_max):
+    """The other frontiers of SURVEY 8(d) C2 on the headline system (the headline line is the real-tree frontier solved
+    cold): the same frontier with every node handed its parent's record (hmpc_warm), the random-prefix generator at
+    p = 0.5 (98 % infeasible: round 2's headline) and p = 0.1, the 1024-node size of BASELINE configs[2], optimal and
+    infeasible nodes apart, and the run-time-sized kernel forced onto the same system (what an MLD without a
+    compile-time instantiation gets)."""
+    from helpers import random_prefix_frontier, make_controller
     T, nub = ctrl.T, ctrl.mld.nub
+    x0_1 = np.array([0., 0., 1., 0.])
     out = {}
-    r, _ = _device_rate(ctrl.qp, x0_h, random_prefix_frontier(T, nub, 4096, p_one=0.1), dev)
+    x0_t, fix_t, par_t = real_tree_frontier(ctrl, 4096, 0, x_max)
+    r, _ = _device_rate(ctrl.qp, x0_t, fix_t, dev, parent=par_t)
+    out['real_trees_4096_handdown'] = r
+    r, _ = _device_rate(ctrl.qp, x0_t[:1024], fix_t[:1024], dev)
+    out['real_trees_1024_configs2_size'] = r
+    r, _ = _device_rate(ctrl.qp, x0_t[:1024], fix_t[:1024], dev, parent=np.where(par_t[:1024] < 1024, par_t[:1024], -1))
+    out['real_trees_1024_handdown'] = r
+    r, _ = _device_rate(ctrl.qp, x0_1, random_prefix_frontier(T, nub, 4096, p_one=0.5), dev)
+    out['random_prefix_p0.5_4096'] = r
+    r, _ = _device_rate(ctrl.qp, x0_1, random_prefix_frontier(T, nub, 4096, p_one=0.1), dev)
     out['random_prefix_p0.1_4096'] = r
-    r, _ = _device_rate(ctrl.qp, x0_h, random_prefix_frontier(T, nub, 1024, p_one=0.5), dev)
+    r, _ = _device_rate(ctrl.qp, x0_1, random_prefix_frontier(T, nub, 1024, p_one=0.5), dev)
     out['random_prefix_p0.5_1024_configs2_size'] = r
-    # replayed real frontier: every node a cold-started search solves from x0 plus its leaves, tiled
-    seen, inner = [], ctrl.solve_frontier
-
-    def recording(identifiers, x0):
-        seen.extend(ctrl._fix_vector(i) for i in identifiers)
-        return inner(identifiers, x0)
-    ctrl.solve_frontier = recording
-    try:
-        _, leaves, _, _ = ctrl.feedforward(x0_h, printing_period=None)
-    finally:
-        ctrl.solve_frontier = inner
-    nodes = np.array(seen + [ctrl._fix_vector(l.identifier) for l in leaves], dtype=np.int8)
-    for size in (1024, 4096):
-        r, _ = _device_rate(ctrl.qp, x0_h, np.tile(nodes, (size // len(nodes) + 1, 1))[:size], dev)
-        out['replayed_real_tree_%d' % size] = r
     # optimal and infeasible nodes apart (the same count of each, drawn from p = 0.1 frontiers)
     pool = random_prefix_frontier(T, nub, 32768, p_one=0.1, seed0=200000)
-    _, status = _device_rate(ctrl.qp, x0_h, pool, dev, reps=1, warm=0)
+    _, status = _device_rate(ctrl.qp, x0_1, pool, dev, reps=1, warm=0)
     n = min(int((status == 0).sum()), 2048)
-    r, _ = _device_rate(ctrl.qp, x0_h, pool[status == 0][:n], dev)
+    r, _ = _device_rate(ctrl.qp, x0_1, pool[status == 0][:n], dev)
     out['optimal_nodes_only'] = r
-    r, _ = _device_rate(ctrl.qp, x0_h, pool[status == 1][:n], dev)
+    r, _ = _device_rate(ctrl.qp, x0_1, pool[status == 1][:n], dev)
     out['infeasible_nodes_only'] = r
+    # the run-time-sized kernel (sparse lists in LDS, row state in a global slab) on the same system and frontier
+    os.environ['HMPC_FORCE_GENERIC'] = '1'
+    try:
+        gen = make_controller('cart_pole_with_walls', backend='hip')
+    finally:
+        del os.environ['HMPC_FORCE_GENERIC']
+    r, _ = _device_rate(gen.qp, x0_t, fix_t, dev, reps=3, warm=1)
+    r['kernel'] = 'hmpc_qp_kernel<0,...> (run-time-sized: any MLD that fits LDS; HMPC_FORCE_GENERIC)'
+    out['real_trees_4096_generic_kernel'] = r
     return out
 
 
@@ -293,22 +322,51 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
     # (d) the C++ fleet driver (hmpc_fleet_*, csrc/hmpc_fleet.hip): trees behind the handle, multiplier rows resident in
     # HBM, one call per step for all loops; same disturbances for every driver (sigma = 0.001, seed = loop index)
     from warm_start_hmpc_amd.fleet import FleetMPC
-    for K, spec in ((1, 4), (64, 2), (256, 0), (1024, 0)):
+    for K, spec, hand in ((1, 4, True), (1, 4, False), (64, 2, True), (256, 0, True), (1024, 0, True), (1024, 0, False)):
         errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
-        fl = FleetMPC(ctrl, K)
+        fl = FleetMPC(ctrl, K, handdown=hand)
         fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], frontier_width=8, speculation=spec)   # warm-up (allocations)
         cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], frontier_width=8, speculation=spec)
         s0 = fl.stats()
         st = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, frontier_width=8, speculation=spec)
         s1 = fl.stats()
         dt = st['wall'] - cold['wall']                                                            # subtract the cold-start step
-        out['fleet_%d_loops' % K] = {'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
-                                     'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'speculation_depth': spec,
-                                     'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
-                                     'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
+        out['fleet_%d_loops%s' % (K, '' if hand else '_no_handdown')] = {
+            'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
+            'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'speculation_depth': spec,
+            'handdown': hand, 'handed_down_verified_per_step': (s1['handed'] - s0['handed']) / (K * (steps + 1.0)),
+            'cold_step_ms': 1e3 * cold['wall'], 'warm_step_ms': 1e3 * dt / steps,
+            'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
+            'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
         del fl
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
+
+
+def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05):
+    """B nodes of real branch-and-bound trees: cold-started searches from x0 = [0, 0, 1, 0] + spread * N(0, 1) * x_max
+    (seed: rank, tree), every node they solve plus their leaves, until B nodes are collected.  Returns (x0 [B, nx],
+    fix [B, T nub], parent [B]: row of the node's parent in this frontier or -1)."""
+    from helpers import real_tree_with_parents
+    xs, fixes, parents, n, j = [], [], [], 0, 0
+    while n < B:
+        rng = np.random.RandomState(7919 * rank + j)
+        x0 = np.array([0., 0., 1., 0.]) + (spread * rng.randn(4) * x_max if (rank or j) else 0.)
+        j += 1
+        fix, parent = real_tree_with_parents(ctrl, x0, leaves_too=True, frontier_width=8)
+        if not len(fix):
+            continue
+        parents.append(np.where(parent >= 0, parent + n, -1))
+        fixes.append(fix)
+        xs.append(np.repeat(x0[None], len(fix), axis=0))
+        n += len(fix)
+    fix, parent, x0 = np.concatenate(fixes)[:B], np.concatenate(parents)[:B].astype(np.int32), np.concatenate(xs)[:B]
+    return np.ascontiguousarray(x0), np.ascontiguousarray(fix), parent
+
+
+def shard(total, world, rank):
+    """Strong scaling (BASELINE configs[2]): node k of a frontier of `total` nodes goes to rank k mod world."""
+    return np.arange(rank, total, world)
 
 
 def main():
@@ -317,7 +375,11 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--frontier', type=int, default=4096, help='nodes per GPU per step')
+    ap.add_argument('--frontier-kind', default='real_tree', choices=('real_tree', 'random_prefix'),
+                    help='real_tree: the nodes real searches solve (default); random_prefix: SURVEY 8(d) C2 generator with --p-one')
     ap.add_argument('--p-one', type=float, default=0.5)
+    ap.add_argument('--handdown', action='store_true',
+                    help='hand every node the record of its parent (hmpc_warm): the parents come from one untimed cold pass')
     ap.add_argument('--frontier-total', type=int, default=0,
                     help='strong scaling: this many nodes IN TOTAL, split over the ranks (BASELINE configs[2]: 1024 over 8 GPUs); '
                          'overrides --frontier')
@@ -333,7 +395,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from helpers import make_controller, random_prefix_frontier
+    from helpers import make_controller, random_prefix_frontier, load_fixture
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -385,9 +447,18 @@ def main():
     else:
         ctrl = make_controller('cart_pole_with_walls', T=40 if args.workload == 'cart_pole_n40' else None, backend='hip', device=local)
         T, nub = ctrl.T, ctrl.mld.nub
-        # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1
-        fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
-        x0_h = np.array([0., 0., 1., 0.])
+        parent_h = None
+        if args.frontier_kind == 'real_tree':
+            if args.frontier_total > 0:    # strong scaling: ONE frontier, node k to rank k mod world (every rank builds it)
+                x0_all, fix_all, _ = real_tree_frontier(ctrl, args.frontier_total, 0, load_fixture('cart_pole_with_walls')['x_max'])
+                mine = shard(args.frontier_total, world, rank)
+                x0_h, fix_h = np.ascontiguousarray(x0_all[mine]), np.ascontiguousarray(fix_all[mine])
+            else:                          # weak scaling: every rank its own trees (seeded by the rank)
+                x0_h, fix_h, parent_h = real_tree_frontier(ctrl, B, rank, load_fixture('cart_pole_with_walls')['x_max'])
+        else:
+            # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1 (strong scaling: of the one frontier)
+            fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
+            x0_h = np.array([0., 0., 1., 0.])
     fix = torch.from_numpy(fix_h).to(dev)
     x0 = torch.from_numpy(x0_h).to(dev)
     out = dict(obj=torch.empty(B, dtype=torch.float64, device=dev), dual_obj=torch.empty(B, dtype=torch.float64, device=dev),
@@ -396,9 +467,18 @@ def main():
                dual=torch.empty(B, ctrl.qp.n_dual, dtype=torch.float64, device=dev))
     fully_fixed = torch.from_numpy((fix_h >= 0).all(axis=1)).to(dev)
     ub = torch.full((1,), float('inf'), dtype=torch.float64, device=dev)
+    warm = None
+    if args.handdown and args.workload == 'cart_pole_n20' and args.frontier_kind == 'real_tree' and parent_h is not None:
+        # one untimed cold pass produces the parents' records; a node is handed its parent's if that is an optimal vertex
+        par = dict(out, primal=torch.empty_like(out['primal']), dual=torch.empty_like(out['dual']))
+        ctrl.qp.solve_batch_device(x0, fix, par)
+        torch.cuda.synchronize()
+        st, itf = par['status'].cpu().numpy(), par['iters'].cpu().numpy()
+        good = (parent_h >= 0) & (st[np.maximum(parent_h, 0)] == 0) & (((itf[np.maximum(parent_h, 0)] >> 16) & 1) > 0)
+        warm = (par['primal'], par['dual'], torch.from_numpy(np.where(good, parent_h, -1).astype(np.int32)).to(dev))
 
     def step():
-        ctrl.qp.solve_batch_device(x0, fix, out)
+        ctrl.qp.solve_batch_device(x0, fix, out, warm=warm)
         # incumbent upper bound = best objective among binary-feasible (fully fixed) nodes,
         # shared over xGMI so that every rank prunes against the global best
         cand = torch.where(fully_fixed, out['obj'], torch.full_like(out['obj'], float('inf')))
@@ -418,7 +498,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         ev[k][0].record()
-        ctrl.qp.solve_batch_device(x0, fix, out)
+        ctrl.qp.solve_batch_device(x0, fix, out, warm=warm)
         ev[k][1].record()
         cand = torch.where(fully_fixed, out['obj'], torch.full_like(out['obj'], float('inf')))
         torch.minimum(ub, cand.min().reshape(1), out=ub)
@@ -434,7 +514,8 @@ def main():
     elapsed = float(t.item())
 
     status = out['status'].cpu().numpy()
-    iters = out['iters'].cpu().numpy() & 0xFFFF          # bit 16 flags a polished record
+    raw_iters = out['iters'].cpu().numpy()
+    iters = raw_iters & 0xFFFF                           # bits 16..18 flag polished / weak / handed-down records
     if rank == 0:
         bytes_per_qp = ctrl.layout.bytes_per_qp()
         value = world * B * args.steps / elapsed
@@ -445,22 +526,26 @@ def main():
         # from the committed summary (profiles/collect.sh + profiles/summarise.py), valid for the default frontier
         traffic, traffic_src = None, None
         try:
-            if B == 4096 and args.p_one == 0.5 and args.workload == 'cart_pole_n20':
+            if B == 4096 and args.frontier_kind == 'real_tree' and not args.handdown and args.workload == 'cart_pole_n20':
                 with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as fh:
                     traffic = json.load(fh)['hbm_traffic_bytes_per_launch']
                 traffic_src = 'profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
         except (OSError, KeyError, ValueError):
             pass
-        polished = int(((out['iters'].cpu().numpy() >> 16) & 1).sum())
+        polished = int(((raw_iters >> 16) & 1).sum())
+        kind = ('nodes of real branch-and-bound trees (every node cold-started searches from perturbed states solve, plus their '
+                'leaves; SURVEY 8d C2 replay frontier)%s' % (', each handed its parent\'s record (hmpc_warm)' if warm is not None else ', each solved cold')
+                if args.frontier_kind == 'real_tree' else 'random-prefix frontier (SURVEY 8d C2), p_one=%.2f' % args.p_one)
         line = {
-            'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic random-binary frontier' if args.workload == 'cart_pole_n20' else 'QP subproblems/sec, ' + args.workload,
+            'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic frontier' if args.workload == 'cart_pole_n20' else 'QP subproblems/sec, ' + args.workload,
             'value': value, 'unit': 'QP subproblems/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': ('strong' if args.frontier_total > 0 else 'weak') if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': ('cart_pole_with_walls N=%d, 4 binaries/step, random-prefix frontier (SURVEY 8d C2), p_one=%.2f' % (T, args.p_one))
+            'config': {'workload': ('cart_pole_with_walls N=%d, 4 binaries/step, %s' % (T, kind))
                        if args.workload != 'random_mld' else 'random MLD nx=20 nu=6+8 N=30 (SURVEY 8d C4), dive frontier',
-                       'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist(), 'parallelism': 'frontier sharded by node, '
+                       'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist() if x0_h.ndim == 1 else 'one initial state per tree: [0, 0, 1, 0] + 0.05 N(0,1) x_max',
+                       'parallelism': 'frontier sharded by node, '
                        'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
                        'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps, active-set polish'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -475,7 +560,9 @@ def main():
                       'frac': 1.2e5 * float(iters.mean()) * B / (kernel_ms * 1e-3) / 1e12 / 78.6,
                       'note': 'neither bandwidth nor flops bound: sequential stage recursions, one wave per SIMD (DESIGN.md 5)'},
             'nodes': {'optimal': int((status == 0).sum()), 'infeasible': int((status == 1).sum()),
-                      'not_converged': int((status > 1).sum()), 'polished': polished, 'ipm_iters_mean': float(iters.mean())},
+                      'not_converged': int((status > 1).sum()), 'polished': polished, 'ipm_iters_mean': float(iters.mean()),
+                      'ipm_iters_mean_optimal': float(iters[status == 0].mean()) if (status == 0).any() else None,
+                      'handed_down_verified': int(((raw_iters >> 18) & 1).sum())},
         }
         if world == 1 and args.workload == 'cart_pole_n20':
             try:  # second kernel of the path (HBM bound), a few milliseconds
@@ -485,7 +572,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.workload == 'cart_pole_n20':
-            for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, x0_h)), ('other_configs', lambda: other_configs(dev)),
+            for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, load_fixture('cart_pole_with_walls')['x_max'])), ('other_configs', lambda: other_configs(dev)),
                             ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl)), ('offline_lps', offline_lps)):
                 try:
                     line[key] = fn()

@@ -56,9 +56,10 @@ int main(void)
     double obj[BATCH], dual_obj[BATCH];
     int32_t status[BATCH], iters[BATCH];
     double *primal = (double *)malloc(sizeof(double) * BATCH * n_primal);
+    double *dual = (double *)malloc(sizeof(double) * BATCH * n_dual);
     hmpc_result out;
-    out.obj = obj; out.dual_obj = dual_obj; out.status = status; out.iters = iters; out.primal = primal; out.dual = NULL;
-    if (hmpc_solve_batch(qp, x0, 0, fix, BATCH, &out) != HMPC_OK) return fail("hmpc_solve_batch");
+    out.obj = obj; out.dual_obj = dual_obj; out.status = status; out.iters = iters; out.primal = primal; out.dual = dual;
+    if (hmpc_solve_batch(qp, x0, 0, fix, BATCH, NULL, &out) != HMPC_OK) return fail("hmpc_solve_batch");
     int bad = 0;
     for (int k = 0; k < BATCH; k++) {
         printf("node %d: status %d, objective %.9f (dual %.9f), %d iterations%s, u_0 = (%.6f, %.6f)\n", k, status[k], obj[k], dual_obj[k],
@@ -70,9 +71,27 @@ int main(void)
     if (obj[1] < obj[0] - 1e-7 || obj[2] < obj[0] - 1e-7) bad = 1;
     /* the fixed binaries come back as fixed */
     if (fabs(primal[1 * n_primal + (HORIZON + 1) * NX + 1] - 0.0) > 1e-9 || fabs(primal[2 * n_primal + (HORIZON + 1) * NX + 1] - 1.0) > 1e-9) bad = 1;
+    /* the two children once more, each handed the record of its parent (node 0): same optimum, and the child whose
+     * optimum lies on the parent's active set needs no interior-point iteration (controller.py:260-264 hands down the
+     * simplex basis; hmpc_warm the parent's record) */
+    if ((iters[0] & HMPC_ITERS_POLISHED) != 0) {
+        const int32_t parent[2] = {0, 0};
+        double wobj[2], wdobj[2];
+        int32_t wstatus[2], witers[2];
+        hmpc_warm warm;
+        warm.primal = primal; warm.dual = dual; warm.index = parent; warm.rows = 1;
+        hmpc_result wout;
+        wout.obj = wobj; wout.dual_obj = wdobj; wout.status = wstatus; wout.iters = witers; wout.primal = NULL; wout.dual = NULL;
+        if (hmpc_solve_batch(qp, x0, 0, fix + HORIZON * NUB, 2, &warm, &wout) != HMPC_OK) return fail("hmpc_solve_batch (hand-down)");
+        for (int k = 0; k < 2; k++) {
+            printf("node %d, parent's record handed down: status %d, objective %.9f, %d iterations%s\n", k + 1, wstatus[k], wobj[k],
+                   witers[k] & 0xFFFF, (witers[k] & HMPC_ITERS_HANDED) ? ", the parent's active set verified" : "");
+            if (wstatus[k] != status[k + 1] || fabs(wobj[k] - obj[k + 1]) > 1e-8 * (1 + fabs(obj[k + 1]))) bad = 1;
+        }
+    }
     /* an impossible initial state: status infeasible, objective +inf, a Farkas objective > 0 */
     const double far[NX] = {50.0, 0.0};
-    if (hmpc_solve_batch(qp, far, 0, fix, 1, &out) != HMPC_OK) return fail("hmpc_solve_batch (infeasible)");
+    if (hmpc_solve_batch(qp, far, 0, fix, 1, NULL, &out) != HMPC_OK) return fail("hmpc_solve_batch (infeasible)");
     printf("x0 outside the state bounds: status %d, objective %f, Farkas objective %.3e\n", status[0], obj[0], dual_obj[0]);
     if (status[0] != HMPC_INFEASIBLE || !isinf(obj[0]) || !(dual_obj[0] > 0)) bad = 1;
     if (hmpc_destroy(qp) != HMPC_OK) return fail("hmpc_destroy");
@@ -89,6 +108,7 @@ int main(void)
         if (lstatus[k] != HMPC_OPTIMAL || fabs(lobj[k] - 2.0) > 1e-12) bad = 1;
     }
     free(primal);
+    free(dual);
     printf(bad ? "c_abi_example: WRONG ANSWER\n" : "c_abi_example: ok\n");
     return bad;
 }

@@ -49,6 +49,7 @@ extern "C" {
 
 #define HMPC_ITERS_POLISHED 0x10000 /* flag in hmpc_result.iters */
 #define HMPC_ITERS_WEAK 0x20000     /* flag in hmpc_result.iters: HMPC_INFEASIBLE, but the ray is no proof to tolerance */
+#define HMPC_ITERS_HANDED 0x40000   /* flag in hmpc_result.iters: the active set handed down by the parent (hmpc_warm) verified */
 
 /* return codes */
 #define HMPC_OK 0
@@ -113,6 +114,26 @@ typedef struct hmpc_result {
     double *dual;     /* B x n_dual                                                           */
 } hmpc_result;
 
+/* Parent -> child hand-down (nullable everywhere).  The reference hands the parent node's simplex basis to the child
+ * (controller.py:260-264, 426; subproblem_solution.py:37-43, with Gurobi's dual simplex); here the child receives the
+ * parent's RECORD: node b tries the active set of row index[b] of (primal, dual) -- rows in the layout of hmpc_result,
+ * e.g. the output arrays of an earlier call; index[b] < 0: nothing handed down -- before its first interior-point
+ * iteration, multipliers and proximal centre from the parent.  A child whose optimum lies on the parent's active set
+ * (the branch that fixes a binary where the relaxation had it) then costs one factorisation and a few solves instead
+ * of ~11 iterations, and returns with HMPC_ITERS_HANDED set; where the set does not verify the node is solved from
+ * the cold start exactly as without the hand-down.  Only records of OPTIMAL nodes flagged HMPC_ITERS_POLISHED may be
+ * handed down (their multipliers are exactly complementary), and only to nodes with the same initial state.  States,
+ * cost and the inputs the cost sees do not depend on the hand-down; where multipliers (dependent active rows) or
+ * cost-free inputs are not unique a handed-down solve may return another optimal choice than a cold one.
+ * Host-pointer form: host arrays of `rows` rows; device-pointer form: device arrays (`rows` unused), and the rows must
+ * not be output rows of the same call. */
+typedef struct hmpc_warm {
+    const double *primal; /* rows x n_primal */
+    const double *dual;   /* rows x n_dual   */
+    const int32_t *index; /* B : row of node b's parent, or -1 */
+    int32_t rows;
+} hmpc_warm;
+
 typedef struct hmpc_handle hmpc_handle;
 
 /* Copies the problem to the device, precomputes scalings and sparse row/column lists.
@@ -131,12 +152,12 @@ int hmpc_record_sizes(const hmpc_handle *h, int32_t *n_primal, int32_t *n_dual);
  * Host-pointer form: copies in, runs, copies out, returns when done.  Replaces
  * B calls of controller.py:229-271. */
 int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_stride, const int8_t *fix, int32_t B,
-                     const hmpc_result *out);
+                     const hmpc_warm *warm /* nullable */, const hmpc_result *out);
 
 /* Device-pointer form: every pointer (x0, fix, and the members of out) is device memory on the
  * handle's device; the launch is asynchronous on `stream` (a hipStream_t, NULL = default stream). */
 int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B,
-                            const hmpc_result *d_out, void *stream);
+                            const hmpc_warm *d_warm /* nullable */, const hmpc_result *d_out, void *stream);
 
 /* ---- Warm-start node shift (reference: controller.py:431-564 construct_warm_start, :615-721) --------
  * After an MPC step the leaves of the branch-and-bound tree become the initial cover of the next
@@ -183,7 +204,9 @@ int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t 
  *                        model's next state A x0 + B u0), solves[k], leaves[k]
  *     hmpc_fleet_shift : the tree becomes the warm start of the next step given the model error e0[k] of the step
  *                        (next state = x1 + e0); cover[k] nodes, reopened[k] of them lost their infeasibility proof
- * Any output pointer may be NULL.  hmpc_fleet_reset(f, k) makes loop k (-1: all) cold again. */
+ * Any output pointer may be NULL.  hmpc_fleet_reset(f, k) makes loop k (-1: all) cold again.  A call that fails midway
+ * (device error, a consumed node that did not converge) leaves some trees advanced and others not: the fleet then refuses
+ * further steps until hmpc_fleet_reset(f, -1). */
 typedef struct hmpc_fleet hmpc_fleet;
 int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out);
 int hmpc_fleet_destroy(hmpc_fleet *f);
@@ -193,6 +216,10 @@ int hmpc_fleet_solve(hmpc_fleet *f, const double *x0 /* K x nx */, int32_t width
 int hmpc_fleet_shift(hmpc_fleet *f, const double *e0 /* K x nx */, int32_t *cover, int32_t *reopened);
 /* kernel launches (rounds) and nodes sent to the QP kernel since creation */
 int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
+/* Parent -> child hand-down inside the fleet's searches (hmpc_warm; on by default): a child that is solved in a later
+ * round than its parent receives the parent's record, which already lies in the fleet's HBM pools.  enable: 1 / 0, < 0:
+ * leave as is.  verified (nullable): solves since creation whose handed-down active set verified. */
+int hmpc_fleet_handdown(hmpc_fleet *f, int32_t enable, int64_t *verified);
 
 /* ---- Incumbent exchange between the GPUs of a node (RCCL over xGMI) ----------------------------------
  * A frontier is sharded by node (node k to rank k mod nranks; nodes are independent, no data-path collective).
@@ -209,6 +236,12 @@ typedef struct hmpc_comm hmpc_comm;
 int hmpc_comm_unique_id(void *id128 /* 128 bytes out */);
 int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out);
 int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub /* in/out */, int32_t *open /* in/out */);
+/* After the last round (once per search; every rank calls it): which rank owns the global incumbent, and its binary
+ * assignment on every rank.  In: *ub this rank's best upper bound (+INFINITY: none), assignment its incumbent's nbytes
+ * bytes (T*nub binaries for this solver; ignored on ranks that do not own the winner).  Out: *ub the global best, *owner
+ * the lowest rank that holds it (-1: no rank has an incumbent, the MIQP is infeasible; assignment untouched), assignment
+ * the owner's bytes on every rank (one ncclBroadcast).  SURVEY.md 8(b)/(e). */
+int hmpc_publish_incumbent(hmpc_comm *c, double *ub /* in/out */, int8_t *assignment /* in/out */, int32_t nbytes, int32_t *owner);
 int hmpc_comm_destroy(hmpc_comm *c);
 
 /* ---- batched dense LPs of the offline terminal ingredients ----

@@ -432,8 +432,17 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 #define POLISH_DELTA 1e-10 /* proximal weight of the inactive rows; must stay above eps * rho            */
 #define POLISH_ITERS 5      /* multiplier steps per active set                                            */
 #define POLISH_ROUNDS 6     /* active sets tried per attempt                                              */
+#ifndef POLISH_ROUNDS_WARM
+#define POLISH_ROUNDS_WARM 3     /* active sets tried when the set is handed down by the parent node */
+#endif
+#ifndef POLISH_WARM_VMAX
+#define POLISH_WARM_VMAX 1e-2
+#endif
 #define POLISH_ATTEMPTS 3   /* attempts per solve (a node whose active set resists is left to the interior-point iterate) */
-static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha)
+/* zwarm (optional, M entries, solver units, tau = 1): multipliers handed down by the parent node -- the active set is
+ * read from them (z > 0: the parent's record is a polished vertex, exactly complementary) instead of from the iterate,
+ * and k->w holds the parent's primal point with the child's prescribed components written over it. */
+static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm)
 {
     int nz = p->nz, T = p->T;
     double rho = POLISH_RHO;
@@ -450,12 +459,12 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
             /* active: z > s, or -- Tapia indicators over the last step (dz in z2, ds in rhs_c) -- the slack shrinks
              * faster than the multiplier: s+/s < z+/z.  The second test reads weakly active rows (both small) right
              * far more often than the first alone: 2.2 instead of 3.3 active sets per polish, no failures on the cart-pole. */
-            int active = k->z[q] > k->s[q];
-            if (last_alpha > 0) {
+            int active = zwarm ? zwarm[q] > 0 : k->z[q] > k->s[q];
+            if (!zwarm && last_alpha > 0) {
                 const double sp = k->s[q] - last_alpha * k->rhs_c[q], zp = k->z[q] - last_alpha * k->z2[q];
                 if (sp > 0 && zp > 0 && k->z[q] * sp > k->s[q] * zp) active = 1;
             }
-            if (active) { k->D[q] = rho; zk[q] = k->z[q] / tau; }
+            if (active) { k->D[q] = rho; zk[q] = (zwarm ? zwarm[q] : k->z[q]) / tau; }
             else { k->D[q] = POLISH_DELTA; zk[q] = 0; }
         }
     }
@@ -465,7 +474,10 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
      * with a violation below es if it was active with a zero multiplier. */
     const double ez = 1e-11, es = 1e-9 * (1 + winf);
     (void)zinf;
-    for (int round = 0; round < POLISH_ROUNDS; round++) {
+    /* (a hand-down that does not verify on the parent's set or after one exchange of rows is dropped: the child's
+     * optimum is elsewhere -- typically the child is infeasible -- and every further round costs an iteration's worth) */
+    const int max_rounds = zwarm ? POLISH_ROUNDS_WARM : POLISH_ROUNDS;
+    for (int round = 0; round < max_rounds; round++) {
         if (factor(p, k, fix) != 0) { return 0; }
         memcpy(cw, cw0, sizeof(double) * p->M); /* the proximal centre starts at the interior-point iterate */
         double pinf = 0, pmove = 0;
@@ -525,8 +537,11 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
             }
         }
         if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      polish round %d vmax %.3e zmin %.3e\n", round, vmax, zmin);
+        /* a handed-down set whose point misses an inactive row by this much is not near the child's optimum (the child is
+         * infeasible, or fixing the binary moved the solution): drop it after this one factorisation */
+        if (zwarm && vmax > POLISH_WARM_VMAX * (1 + winf)) return 0;
         if (vmax <= es && zmin >= -ez) {
-            if (level == 1 && round + 1 < POLISH_ROUNDS) {
+            if (level == 1 && round + 1 < max_rounds) {
                 /* verified at the second level: the same active set once more at the first, from these multipliers --
                  * what is left of them to settle are the components that matter (C_A' dz of the size of the rounding of
                  * the second level); the ones that were slow are already in place */
@@ -552,6 +567,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
 
 /* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
 static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, int do_polish, double ptol, double tol, double tol_inf, int max_iter,
+                     const double *wprimal, const double *wdual,
                      double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol, int *polished_out)
 {
     int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
@@ -575,6 +591,40 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
 
     int status = ST_MAXITER, it = 0, extra_done = 0, polished = 0, npol = 0, weak = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
+    /* ---- Parent -> child hand-down (the reference hands the parent's simplex basis to the child, controller.py:260-264,
+     * subproblem_solution.py:37-43).  wprimal / wdual: the PARENT's record (output conventions).  Its active set -- the rows
+     * with a positive multiplier, minus the bound rows of binaries the child fixes -- is tried by the polish before the
+     * first interior-point iteration, multipliers and proximal centre from the parent; a child whose optimum lies on the
+     * same active set (the branch that fixes a binary where the relaxation had it) verifies after one factorisation and a
+     * few solves.  Otherwise nothing has happened: the cold start below is untouched. */
+    if (wprimal && wdual && do_polish) {
+        double *zw = k->z2;
+        const double *mu_w = wdual + (T + 1) * nx; const int nmu_w = (T - 1) * p->nc + p->ncL;
+        const double *nlb_w = mu_w + nmu_w, *nub_w = nlb_w + T * nub;
+        double winf0 = 0, zinf0 = 0;
+        for (int t = 0; t <= T; t++) for (int i = 0; i < nx; i++) k->w[t * nz + i] = wprimal[t * nx + i];
+        for (int t = 0; t < T; t++) for (int i = 0; i < nu; i++) k->w[t * nz + nx + i] = wprimal[(T + 1) * nx + t * nu + i];
+        for (int i = 0; i < nx; i++) k->w[i] = x0[i];
+        for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b];
+        for (int i = 0; i < n; i++) if (fabs(k->w[i]) > winf0) winf0 = fabs(k->w[i]);
+        for (int t = 0; t < T; t++) {
+            int m = mt(p, t), mg = m - 2 * nub, ro = p->roff[t]; const double *sc = t < T - 1 ? p->sreg : p->slast;
+            for (int r = 0; r < m; r++) {
+                double v = 0;
+                if (k->act[ro + r]) {
+                    if (r < mg) v = mu_w[t * p->nc + r] * p->cs / sc[r];
+                    else if (r < mg + nub) v = nlb_w[t * nub + (r - mg)] * p->cs;
+                    else v = nub_w[t * nub + (r - mg - nub)] * p->cs;
+                }
+                zw[ro + r] = v; if (v > zinf0) zinf0 = v;
+            }
+        }
+        for (int i = 0; i < (T + 1) * nx; i++) if (fabs(wdual[i]) * p->cs > zinf0) zinf0 = fabs(wdual[i]) * p->cs;
+        if (winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
+        memset(k->w, 0, sizeof(double) * n);
+        for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
+        for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
+    }
     double hinf = fmax(vmaxabs(p->hreg, p->mreg), vmaxabs(p->hlast, p->mlast));
     double x0inf = vmaxabs(x0, nx);
     (void)hinf;
@@ -650,7 +700,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             const int ready = do_polish && (npol < POLISH_ATTEMPTS ? (acceptable || exhausted || (status != ST_OPTIMAL && rcinf / tau <= ptol * (1 + winf + x0inf) &&
                                                                         rdinf / tau <= ptol * (1 + zinf) && gap <= gptol))
                                                                    : (npol == POLISH_ATTEMPTS && final_exit));
-            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha)) { status = ST_OPTIMAL; polished = npol; break; } }
+            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha, NULL)) { status = ST_OPTIMAL; polished = npol; break; } }
             if (acceptable) {
                 status = ST_OPTIMAL;
                 if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tol * (1 + zinf)) || extra_done >= 3 || it == max_iter) break;
@@ -786,6 +836,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         if (!(tau > 0) || !(kap >= 0) || tau != tau) { status = ST_NUMERICAL; break; }
         if (status == ST_OPTIMAL && it + 1 > max_iter) break;
     }
+output:
     *iters = it;
     if (polished) { /* the polished point replaces the iterate (tau = 1 units; exactly complementary) */
         memcpy(k->w, k->w1, sizeof(double) * n); memcpy(k->lam, k->lam1, sizeof(double) * (T + 1) * nx);
@@ -868,6 +919,7 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
                        const double *Q, const double *R, const double *QT,
                        const double *x0, int x0_stride, int nbatch, const int8_t *fix,
                        double tol, double tol_inf, int max_iter, int nthreads, int lazy_terminal, int refine, int do_polish, double ptol,
+                       const double *warm_primal, const double *warm_dual, const int32_t *warm_index,
                        double *obj, double *dobj, int *status, int *iters, double *primal, double *dual, int *polished)
 {
     if (nx + nu > 64 || nx > 32) return -1;
@@ -889,11 +941,15 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
              * of the node.  Otherwise solve again with every row. */
             const double *xb = x0 + (size_t)b * x0_stride; const int8_t *fb = fix + (size_t)b * T * nub;
             double *pb = primal + (size_t)b * np_, *db = dual + (size_t)b * nd, tv = 0; int it1 = 0, it2 = 0, st, pol = 0;
+            /* the parent's record, if one is handed down (rows of warm_primal / warm_dual; may be the output arrays of an
+             * earlier call, never rows of this call's outputs) */
+            const int wi = (warm_index && warm_primal && warm_dual) ? warm_index[b] : -1;
+            const double *wp = wi >= 0 ? warm_primal + (size_t)wi * np_ : NULL, *wd = wi >= 0 ? warm_dual + (size_t)wi * nd : NULL;
             if (ncL > nc && lazy_terminal) {
-                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
                 if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)))
-                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
-            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
+            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
             status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol;
         }
         work_free(k);

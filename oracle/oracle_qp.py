@@ -30,6 +30,7 @@ def _load():
     lib.oracle_solve_batch.argtypes = [ctypes.c_int] * 9 + [dp] * 11 + [dp, ctypes.c_int, ctypes.c_int,
                                                                        ctypes.POINTER(ctypes.c_int8),
                                                                        ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                                                       dp, dp, ctypes.POINTER(ctypes.c_int32),
                                                                        dp, dp, ctypes.POINTER(ctypes.c_int),
                                                                        ctypes.POINTER(ctypes.c_int), dp, dp, ctypes.POINTER(ctypes.c_int)]
     return lib
@@ -66,7 +67,9 @@ class OracleBatchedQP(object):
         self.n_primal = (T + 1) * nx + T * nu
         self.n_dual = (T + 1) * nx + (T - 1) * nc + ncL + 2 * T * nub + T * nq + nqT + T * nr
 
-    def solve_batch(self, x0, fix):
+    def solve_batch(self, x0, fix, warm=None):
+        """warm: optional (primal rows, dual rows, index) -- per node the row of its PARENT's record in the two arrays
+        (-1: none), the hand-down of hmpc_warm (include/hmpc.h)."""
         p = self.p
         fix = np.ascontiguousarray(fix, dtype=np.int8)
         B = fix.shape[0]
@@ -75,12 +78,21 @@ class OracleBatchedQP(object):
         out = dict(obj=np.empty(B), dual_obj=np.empty(B), status=np.empty(B, dtype=np.int32),
                    iters=np.empty(B, dtype=np.int32), primal=np.empty((B, self.n_primal)),
                    dual=np.empty((B, self.n_dual)), polished=np.zeros(B, dtype=np.int32))
+        if warm is not None:
+            wp = np.ascontiguousarray(warm[0], dtype=np.float64).reshape(-1, self.n_primal)
+            wd = np.ascontiguousarray(warm[1], dtype=np.float64).reshape(-1, self.n_dual)
+            wi = np.ascontiguousarray(warm[2], dtype=np.int32)
+            assert wi.shape == (B,) and wp.shape[0] == wd.shape[0] and (wi.max(initial=-1) < wp.shape[0])
+            wargs = (_d(wp), _d(wd), wi.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        else:
+            wargs = (None, None, None)
         tic = time.perf_counter()
         rc = self.lib.oracle_solve_batch(
             *self.sizes, _d(p['A']), _d(p['B']), _d(p['F']), _d(p['G']), _d(p['h']),
             _d(p['F_Tm1']), _d(p['G_Tm1']), _d(p['h_Tm1']), _d(p['Q']), _d(p['R']), _d(p['Q_T']),
             _d(x0), stride, B, fix.ctypes.data_as(ctypes.POINTER(ctypes.c_int8)),
             self.tol, self.tol_inf, self.max_iter, self.threads, self.lazy_terminal, self.refine, self.polish, self.polish_tol,
+            *wargs,
             _d(out['obj']), _d(out['dual_obj']), out['status'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
             out['iters'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)), _d(out['primal']), _d(out['dual']),
             out['polished'].ctypes.data_as(ctypes.POINTER(ctypes.c_int)))

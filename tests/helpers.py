@@ -171,3 +171,33 @@ def exercise_bounded_qp(ctrl):
     qp.set_constraint_rhs('nu_ub_1', [.5, 1., 1., 1.])
     with pytest.raises(ValueError, match='free'):
         qp.optimize()
+
+
+def real_tree_with_parents(ctrl, x0, leaves_too=False, **search):
+    """Every node a cold-started branch and bound solves from x0, in solve order (and its leaves, on request), with the
+    index of each node's parent among them (-1: the root, or a parent that is not in the list) -- the frontier of
+    SURVEY.md 8(d) C2 "replayed real tree", and the shape in which the parent -> child hand-down (hmpc_warm) applies.
+    Returns (fix int8 [n, T nub], parent int32 [n])."""
+    seen, inner = [], ctrl.solve_frontier
+
+    def recording(identifiers, x, *a, **k):
+        seen.extend(ctrl._fix_vector(i) for i in identifiers)
+        return inner(identifiers, x, *a, **k)
+    ctrl.solve_frontier = recording
+    try:
+        _, leaves, _, _ = ctrl.feedforward(x0, printing_period=None, **search)
+    finally:
+        ctrl.solve_frontier = inner
+    rows = seen + ([ctrl._fix_vector(l.identifier) for l in leaves] if leaves_too else [])
+    fix = np.array(rows, dtype=np.int8)
+    where = {}
+    for i, f in enumerate(fix[:len(seen)]):
+        where.setdefault(f.tobytes(), i)
+    parent = np.full(len(fix), -1, dtype=np.int32)
+    for i, f in enumerate(fix):
+        d = int((f >= 0).sum())
+        if d:
+            g = f.copy()
+            g[d - 1] = -1
+            parent[i] = where.get(g.tobytes(), -1)
+    return fix, parent

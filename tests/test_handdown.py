@@ -1,0 +1,111 @@
+"""Parent -> child hand-down of active sets (``hmpc_warm``, include/hmpc.h) -- this repository's form of the reference's
+optional simplex-basis hand-down (warm_start_hmpc/controller.py:260-264, 426; subproblem_solution.py:37-43): a child node
+receives its parent's record and tries the parent's active set before its first interior-point iteration.
+
+What must hold: statuses are those of the cold solves; objectives, states and the inputs the cost sees agree (the vertex
+of a verified active set does not depend on where the set came from); a child whose optimum lies on the parent's set
+costs no interior-point iteration; the tree search returns the same incumbent with the same number of solves."""
+import numpy as np
+import pytest
+
+from helpers import make_controller, real_tree_with_parents
+
+X0 = np.array([0., 0., 1., 0.])
+
+
+def _handed_down(ctrl, fix, parent, cold):
+    ok = (parent >= 0) & (cold['status'][np.maximum(parent, 0)] == 0) & (cold['polished'][np.maximum(parent, 0)] > 0)
+    index = np.where(ok, parent, -1).astype(np.int32)
+    return index, ctrl.qp.solve_batch(X0, fix, warm=(cold['primal'], cold['dual'], index))
+
+
+def _check(ctrl, fix, index, cold, warm, T, min_hits):
+    nx = ctrl.mld.nx
+    assert np.array_equal(cold['status'], warm['status'])
+    opt = cold['status'] == 0
+    np.testing.assert_allclose(warm['obj'][opt], cold['obj'][opt], rtol=1e-9, atol=1e-12)
+    xs = slice(0, (T + 1) * nx)
+    assert np.max(np.abs(warm['primal'][opt][:, xs] - cold['primal'][opt][:, xs])) < 1e-7
+    inf = cold['status'] == 1                                            # nothing is handed to a ray: bit-equal records
+    assert np.array_equal(warm['dual'][inf], cold['dual'][inf]) and np.array_equal(warm['iters'][inf], cold['iters'][inf])
+    handed = opt & (index >= 0)
+    hits = handed & (warm['iters'] == 0)
+    assert hits.sum() >= min_hits * handed.sum(), (hits.sum(), handed.sum())
+    assert np.all(warm['polished'][hits] > 0)
+    none = index < 0                                                     # nodes without a parent record: the cold solve
+    assert np.array_equal(warm['obj'][none], cold['obj'][none]) and np.array_equal(warm['iters'][none], cold['iters'][none])
+    return int(hits.sum()), int(handed.sum())
+
+
+@pytest.mark.parametrize('fixture,T', [('cart_pole_with_walls', 20), ('cart_pole_with_walls', 10), ('cart_pole_one_wall', 40)])
+def test_handed_down_active_sets_on_the_oracle(fixture, T):
+    ctrl = make_controller(fixture, T=T, backend='oracle', threads=8)
+    x0 = np.array([0., 0., .5, 0.]) if T == 10 else X0
+    fix, parent = real_tree_with_parents(ctrl, x0)
+    cold = ctrl.qp.solve_batch(x0, fix)
+    ok = (parent >= 0) & (cold['status'][np.maximum(parent, 0)] == 0) & (cold['polished'][np.maximum(parent, 0)] > 0)
+    index = np.where(ok, parent, -1).astype(np.int32)
+    warm = ctrl.qp.solve_batch(x0, fix, warm=(cold['primal'], cold['dual'], index))
+    hits, handed = _check(ctrl, fix, index, cold, warm, T, min_hits=0.5)
+    opt = cold['status'] == 0
+    assert warm['iters'][opt].mean() < 0.5 * cold['iters'][opt].mean()  # the target of the hand-down: optimal children >= 2x
+
+
+def test_tree_search_with_hand_down_on_the_oracle():
+    ctrl = make_controller('cart_pole_with_walls', backend='oracle', threads=1)
+    a = ctrl.feedforward(X0, printing_period=None)
+    b = ctrl.feedforward(X0, printing_period=None, handdown=True)
+    assert a[2] == b[2] and len(a[1]) == len(b[1])                       # same solves, same leaves
+    assert abs(a[0].objective - b[0].objective) <= 1e-12
+    assert np.array_equal(np.concatenate(a[0].variables['ub']), np.concatenate(b[0].variables['ub']))
+    assert np.max(np.abs(np.array(a[0].variables['x']) - np.array(b[0].variables['x']))) < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('fixture,T', [('cart_pole_with_walls', 20), ('cart_pole_with_walls', 40), ('cart_pole_one_wall', 40)])
+def test_handed_down_active_sets_on_the_gpu(fixture, T):
+    hip = make_controller(fixture, T=T, backend='hip')
+    orc = make_controller(fixture, T=T, backend='oracle', threads=8)
+    fix, parent = real_tree_with_parents(orc, X0)
+    cold = hip.qp.solve_batch(X0, fix)
+    ok = (parent >= 0) & (cold['status'][np.maximum(parent, 0)] == 0) & (cold['polished'][np.maximum(parent, 0)] > 0)
+    index = np.where(ok, parent, -1).astype(np.int32)
+    warm = hip.qp.solve_batch(X0, fix, warm=(cold['primal'], cold['dual'], index))
+    hits, handed = _check(hip, fix, index, cold, warm, T, min_hits=0.5)
+    assert np.array_equal(warm['handed'] > 0, (warm['iters'] == 0) & (index >= 0) & (cold['status'] == 0))
+    # the same hand-down on the oracle: same nodes verify, same vertices
+    oc = orc.qp.solve_batch(X0, fix)
+    ow = orc.qp.solve_batch(X0, fix, warm=(oc['primal'], oc['dual'], index))
+    assert np.array_equal(ow['status'], warm['status'])
+    assert np.mean((ow['iters'] == 0) == (warm['iters'] == 0)) > 0.97
+    opt = cold['status'] == 0
+    nxs = (T + 1) * hip.mld.nx
+    assert np.max(np.abs(ow['primal'][opt][:, :nxs] - warm['primal'][opt][:, :nxs])) < 1e-6
+
+
+@pytest.mark.gpu
+def test_hand_down_in_the_device_pointer_form_and_in_the_tree_search():
+    import torch
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    fix, parent = real_tree_with_parents(hip, X0)
+    cold = hip.qp.solve_batch(X0, fix)
+    ok = (parent >= 0) & (cold['status'][np.maximum(parent, 0)] == 0) & (cold['polished'][np.maximum(parent, 0)] > 0)
+    index = np.where(ok, parent, -1).astype(np.int32)
+    host = hip.qp.solve_batch(X0, fix, warm=(cold['primal'], cold['dual'], index))
+    dev = torch.device('cuda')
+    B = len(fix)
+    out = dict(obj=torch.empty(B, dtype=torch.float64, device=dev), dual_obj=torch.empty(B, dtype=torch.float64, device=dev),
+               status=torch.empty(B, dtype=torch.int32, device=dev), iters=torch.empty(B, dtype=torch.int32, device=dev),
+               primal=torch.empty(B, hip.qp.n_primal, dtype=torch.float64, device=dev),
+               dual=torch.empty(B, hip.qp.n_dual, dtype=torch.float64, device=dev))
+    wp, wd, wi = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (cold['primal'], cold['dual'], index))
+    hip.qp.solve_batch_device(torch.from_numpy(X0).to(dev), torch.from_numpy(fix).to(dev), out, warm=(wp, wd, wi))
+    torch.cuda.synchronize()
+    assert np.array_equal(out['status'].cpu().numpy(), host['status'])
+    assert np.array_equal(out['iters'].cpu().numpy() & 0xFFFF, host['iters'])
+    assert np.array_equal(out['obj'].cpu().numpy(), host['obj'])           # same records through both entry points
+    # the tree search with the hand-down: same incumbent, same number of solves, fewer iterations
+    a = hip.feedforward(X0, printing_period=None)
+    b = hip.feedforward(X0, printing_period=None, handdown=True)
+    assert a[2] == b[2] and abs(a[0].objective - b[0].objective) <= 1e-10
+    assert np.array_equal(np.concatenate(a[0].variables['ub']), np.concatenate(b[0].variables['ub']))

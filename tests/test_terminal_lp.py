@@ -115,6 +115,13 @@ def _check_multiplier_map(lp):
     # one wall: the optimum is unique there, the committed map (HiGHS, dual simplex) is reproduced
     d, E, R = _ingredients('cart_pole_one_wall')
     np.testing.assert_allclose(M, d['M'], atol=1e-12)
+    # multipliers that are not unique, next to a row that is feasible but NOT optimal: r = (1, 1) is e_1 + e_2 (cost 2),
+    # row 3 (cost 2: the optimal face has two vertices) or row 4 (the same direction at cost 3).  The least-weight pick
+    # must stay on the optimal face -- row 4 gets nothing, however small the value the first launch left on it
+    F = np.array([[1., 0.], [0., 1.], [1., 1.], [1., 1.]]); G = np.zeros((4, 1)); h = np.array([1., 1., 2., 3.])
+    M = ts.update_mu(F, G, h, np.array([[1., 1.]]), np.zeros((1, 1)), lp=lp)
+    np.testing.assert_allclose(F.T.dot(M[:, 0]), [1., 1.], atol=1e-12)
+    assert abs(h.dot(M[:, 0]) - 2.) < 1e-12 and M[3, 0] == 0. and M.min() >= 0.
     # a row outside the conic hull: the reference's ValueError (controller.py:223-224)
     F = np.array([[1., 0.], [0., 1.]]); G = np.zeros((2, 1)); h = np.ones(2)
     with pytest.raises(ValueError):

@@ -55,6 +55,7 @@ struct hmpc_handle {
     void *d_x0 = nullptr;    // one device block (inputs, then outputs: stage_layout)
     void *h_stage = nullptr; // its pinned host mirror
     int staged = 0;
+    bool staged_warm = false; // the blocks have room for one handed-down parent record per node
 };
 
 namespace {
@@ -518,7 +519,7 @@ extern "C" int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *ld
 }
 
 extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix,
-                                       int32_t B, const hmpc_result *d_out, void *stream)
+                                       int32_t B, const hmpc_warm *d_warm, const hmpc_result *d_out, void *stream)
 {
     g_err.clear();
     if (!h || !d_x0 || !d_fix || !d_out) return fail(HMPC_EINVAL, "null argument");
@@ -526,6 +527,11 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
+    DevWarm w{nullptr, nullptr, nullptr};
+    if (d_warm && d_warm->index) {
+        if (!d_warm->primal || !d_warm->dual) return fail(HMPC_EINVAL, "hmpc_warm: index without record rows");
+        w = DevWarm{d_warm->primal, d_warm->dual, d_warm->index};
+    }
     int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
     // the streaming form holds one node per CU whatever the number of waves: always spread it over all four SIMDs
     if (h->cfg[2].k.big && !getenv("HMPC_WAVES")) nw = 4;
@@ -551,7 +557,7 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
         hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order);
     }
     hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
-                       d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order);
+                       d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order, w);
     HIPCHK(hipGetLastError());
     return HMPC_OK;
 }
@@ -560,15 +566,19 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
 // the order obj | dual_obj | status | iters | primal | dual -- one copy up, one copy down per call (round 1: two pageable
 // copies up, six down, each its own synchronisation: ~100 us of a 1.4 ms branch-and-bound round).
 struct StageLayout {
-    size_t x0, fix, obj, dobj, status, iters, primal, dual, in_bytes, total;
+    size_t x0, fix, widx, wprim, wdual, obj, dobj, status, iters, primal, dual, in_bytes, total;
 };
-static StageLayout stage_layout(const DevProb &p, size_t B)
+// nw: parent records handed down with the batch (gathered: one row per node that has one)
+static StageLayout stage_layout(const DevProb &p, size_t B, size_t nw = 0)
 {
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     StageLayout L;
     L.x0 = 0;
     L.fix = up(B * p.nx * sizeof(double));
-    L.in_bytes = L.fix + up(B * (size_t)p.T * p.nub + 1);
+    L.widx = L.fix + up(B * (size_t)p.T * p.nub + 1);
+    L.wprim = L.widx + (nw ? up(B * sizeof(int32_t)) : 0);
+    L.wdual = L.wprim + up(nw * (size_t)p.n_primal * sizeof(double));
+    L.in_bytes = L.wdual + up(nw * (size_t)p.n_dual * sizeof(double));
     L.obj = L.in_bytes;
     L.dobj = L.obj + up(B * sizeof(double));
     L.status = L.dobj + up(B * sizeof(double));
@@ -579,22 +589,25 @@ static StageLayout stage_layout(const DevProb &p, size_t B)
     return L;
 }
 
-static int ensure_staging(hmpc_handle *h, int B)
+static int ensure_staging(hmpc_handle *h, int B, bool with_warm)
 {
-    if (B <= h->staged) return HMPC_OK;
+    if (B <= h->staged && (!with_warm || h->staged_warm)) return HMPC_OK;
     if (h->d_x0) { (void)hipFree(h->d_x0); h->d_x0 = nullptr; }
     if (h->h_stage) { (void)hipHostFree(h->h_stage); h->h_stage = nullptr; }
+    const int want = B > h->staged ? B : h->staged;
     h->staged = 0;
-    const int cap = B < 64 ? 64 : B + B / 4;
-    const StageLayout L = stage_layout(h->dp, (size_t)cap);
+    const int cap = want < 64 ? 64 : want + want / 4;
+    with_warm = with_warm || h->staged_warm;
+    const StageLayout L = stage_layout(h->dp, (size_t)cap, with_warm ? (size_t)cap : 0);
     HIPCHK(hipMalloc(&h->d_x0, L.total));
     HIPCHK(hipHostMalloc(&h->h_stage, L.total, hipHostMallocDefault));
     h->staged = cap;
+    h->staged_warm = with_warm;
     return HMPC_OK;
 }
 
 extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_stride, const int8_t *fix, int32_t B,
-                                const hmpc_result *out)
+                                const hmpc_warm *warm, const hmpc_result *out)
 {
     g_err.clear();
     if (!h || !x0 || !fix || !out) return fail(HMPC_EINVAL, "null argument");
@@ -602,21 +615,45 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
     const DevProb &p = h->dp;
-    int rc = ensure_staging(h, B);
+    // parent records handed down: gathered, one row per node that has one (the index is rewritten to the gathered rows)
+    size_t nwarm = 0;
+    if (warm && warm->index) {
+        if (!warm->primal || !warm->dual) return fail(HMPC_EINVAL, "hmpc_warm: index without record rows");
+        for (int b = 0; b < B; b++) {
+            if (warm->index[b] >= warm->rows) return fail(HMPC_EINVAL, "hmpc_warm: index beyond the rows handed in");
+            nwarm += warm->index[b] >= 0;
+        }
+    }
+    int rc = ensure_staging(h, B, nwarm > 0);
     if (rc) return rc;
     // offsets of THIS batch (they always fit the capacity the blocks were allocated for): with the capacity's offsets
     // a small branch-and-bound round after one large call dragged the whole capacity-sized primal region along
-    const StageLayout L = stage_layout(p, (size_t)B);
+    const StageLayout L = stage_layout(p, (size_t)B, nwarm);
     char *hs = (char *)h->h_stage, *ds = (char *)h->d_x0;
     const size_t nfix = (size_t)p.T * p.nub;
     if (x0_stride == 0) std::memcpy(hs + L.x0, x0, p.nx * sizeof(double));
     else
         for (int b = 0; b < B; b++) std::memcpy(hs + L.x0 + (size_t)b * p.nx * sizeof(double), x0 + (size_t)b * x0_stride, p.nx * sizeof(double));
     std::memcpy(hs + L.fix, fix, (size_t)B * nfix);
+    hmpc_warm dw{nullptr, nullptr, nullptr, 0};
+    if (nwarm) {
+        int32_t *idx = (int32_t *)(hs + L.widx);
+        size_t q = 0;
+        for (int b = 0; b < B; b++) {
+            const int32_t r = warm->index[b];
+            idx[b] = r >= 0 ? (int32_t)q : -1;
+            if (r < 0) continue;
+            std::memcpy(hs + L.wprim + q * p.n_primal * sizeof(double), warm->primal + (size_t)r * p.n_primal, p.n_primal * sizeof(double));
+            std::memcpy(hs + L.wdual + q * p.n_dual * sizeof(double), warm->dual + (size_t)r * p.n_dual, p.n_dual * sizeof(double));
+            q++;
+        }
+        dw = hmpc_warm{(const double *)(ds + L.wprim), (const double *)(ds + L.wdual), (const int32_t *)(ds + L.widx), (int32_t)nwarm};
+    }
     HIPCHK(hipMemcpyAsync(ds, hs, L.in_bytes, hipMemcpyHostToDevice, nullptr));
     hmpc_result d{(double *)(ds + L.obj), (double *)(ds + L.dobj), (int32_t *)(ds + L.status), (int32_t *)(ds + L.iters),
                   out->primal ? (double *)(ds + L.primal) : nullptr, out->dual ? (double *)(ds + L.dual) : nullptr};
-    rc = hmpc_solve_batch_device(h, (const double *)(ds + L.x0), x0_stride == 0 ? 0 : p.nx, (const int8_t *)(ds + L.fix), B, &d, nullptr);
+    rc = hmpc_solve_batch_device(h, (const double *)(ds + L.x0), x0_stride == 0 ? 0 : p.nx, (const int8_t *)(ds + L.fix), B,
+                                 nwarm ? &dw : nullptr, &d, nullptr);
     if (rc) return rc;
     // small outputs in one copy through the pinned block; large primal / dual blocks straight into the caller's arrays
     // (a pageable copy is pipelined by the runtime, a detour through the staging block would not be)

@@ -3,7 +3,8 @@
 // The reference is single-process; sharding a frontier over the GPUs of a node is new.  Nodes are
 // independent, so the only exchange is, once per branch-and-bound round, MIN over two float64 per rank,
 // (upper bound, -open candidates): every rank then prunes against the global best and all ranks stop in the same round
-// (the Python form is warm_start_hmpc_amd/distributed.py::IncumbentExchange).  8-byte messages: latency bound on xGMI,
+// (the Python form is warm_start_hmpc_amd/distributed.py::IncumbentExchange); once per search the owner of the global
+// incumbent is determined and its binary assignment broadcast (hmpc_publish_incumbent).  8-byte messages: latency bound on xGMI,
 // bandwidth is irrelevant.  RCCL is bound at run time (dlopen): a process that never creates a communicator does not
 // need the library, and a process that already loaded RCCL (PyTorch) shares that copy.
 #include <dlfcn.h>
@@ -13,8 +14,12 @@ struct hmpc_comm {
     void *lib = nullptr;
     void *comm = nullptr; // ncclComm_t
     double *d_pair = nullptr, *h_pair = nullptr;
+    int8_t *d_bytes = nullptr;
+    size_t cap_bytes = 0;
+    int rank = 0, nranks = 1;
     hipStream_t stream = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
@@ -49,13 +54,16 @@ extern "C" int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, co
     HIPCHK(hipSetDevice(h->device));
     hmpc_comm *c = new hmpc_comm();
     c->h = h;
+    c->rank = rank;
+    c->nranks = nranks;
     c->lib = rccl_open();
     if (!c->lib) { delete c; return fail(HMPC_EDEVICE, "comm: cannot load RCCL"); }
     auto init = (int (*)(void **, int, RcclId, int))dlsym(c->lib, "ncclCommInitRank");
     c->AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(c->lib, "ncclAllReduce");
+    c->Broadcast = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(c->lib, "ncclBroadcast");
     c->CommDestroy = (int (*)(void *))dlsym(c->lib, "ncclCommDestroy");
     c->GetErrorString = (const char *(*)(int))dlsym(c->lib, "ncclGetErrorString");
-    if (!init || !c->AllReduce || !c->CommDestroy) { delete c; return fail(HMPC_EDEVICE, "comm: RCCL symbols not found"); }
+    if (!init || !c->AllReduce || !c->Broadcast || !c->CommDestroy) { delete c; return fail(HMPC_EDEVICE, "comm: RCCL symbols not found"); }
     RcclId id;
     std::memcpy(id.bytes, id128, sizeof id.bytes);
     const int rc = init(&c->comm, nranks, id, rank);
@@ -90,6 +98,51 @@ extern "C" int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub, int32_t *open)
     return HMPC_OK;
 }
 
+// Who owns the global incumbent, and its binary assignment on every rank ("pack (ub, rank) ... or
+// follow with ncclBroadcast of the <= T nub byte winning identifier from the owner").  One all-reduce (MIN) of
+// (ub, rank if this rank's bound equals ... ) cannot be had in one step without knowing the minimum, so: MIN over the
+// bounds, then MIN over the ranks that hold it, then one broadcast of the owner's bytes -- three 8 / 8 / T nub byte
+// messages, once per search (not per round).
+extern "C" int hmpc_publish_incumbent(hmpc_comm *c, double *ub, int8_t *assignment, int32_t nbytes, int32_t *owner)
+{
+    g_err.clear();
+    if (!c || !ub || !owner || nbytes < 0 || (nbytes > 0 && !assignment)) return fail(HMPC_EINVAL, "comm: bad argument");
+    HIPCHK(hipSetDevice(c->h->device));
+    auto reduce_min = [&](double v, double &out) -> int {
+        c->h_pair[0] = v;
+        HIPCHK(hipMemcpyAsync(c->d_pair, c->h_pair, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        const int rc = c->AllReduce(c->d_pair, c->d_pair, 1, /* ncclFloat64 */ 8, /* ncclMin */ 3, c->comm, c->stream);
+        if (rc != 0) return fail(HMPC_EDEVICE, std::string("comm: ncclAllReduce failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?"));
+        HIPCHK(hipMemcpyAsync(c->h_pair, c->d_pair, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        out = c->h_pair[0];
+        return HMPC_OK;
+    };
+    const double mine = *ub;
+    double best = 0, who = 0;
+    int rc;
+    if ((rc = reduce_min(mine, best))) return rc;
+    // the lowest rank among those that hold the best bound (ties between ranks are possible: equal optima)
+    if ((rc = reduce_min((mine == best && std::isfinite(mine)) ? (double)c->rank : (double)c->nranks, who))) return rc;
+    *ub = best;
+    if (who >= (double)c->nranks) { *owner = -1; return HMPC_OK; } // no rank has an incumbent: the problem is infeasible
+    *owner = (int32_t)who;
+    if (nbytes == 0) return HMPC_OK;
+    if ((size_t)nbytes > c->cap_bytes) {
+        if (c->d_bytes) (void)hipFree(c->d_bytes);
+        c->d_bytes = nullptr;
+        c->cap_bytes = 0;
+        HIPCHK(hipMalloc((void **)&c->d_bytes, (size_t)nbytes));
+        c->cap_bytes = (size_t)nbytes;
+    }
+    if (c->rank == *owner) HIPCHK(hipMemcpyAsync(c->d_bytes, assignment, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    rc = c->Broadcast(c->d_bytes, c->d_bytes, (size_t)nbytes, /* ncclInt8 */ 0, *owner, c->comm, c->stream);
+    if (rc != 0) return fail(HMPC_EDEVICE, std::string("comm: ncclBroadcast failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?"));
+    HIPCHK(hipMemcpyAsync(assignment, c->d_bytes, (size_t)nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return HMPC_OK;
+}
+
 extern "C" int hmpc_comm_destroy(hmpc_comm *c)
 {
     if (!c) return HMPC_OK;
@@ -97,6 +150,7 @@ extern "C" int hmpc_comm_destroy(hmpc_comm *c)
     if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
     if (c->comm && c->CommDestroy) (void)c->CommDestroy(c->comm);
     if (c->d_pair) (void)hipFree(c->d_pair);
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->h_pair) (void)hipHostFree(c->h_pair);
     delete c;
     return HMPC_OK;

@@ -57,6 +57,13 @@ struct DevOut {
     double *primal, *dual;
 };
 
+// Parent records handed down to the nodes of a launch (hmpc_warm): node b tries the active set of row index[b] of
+// (primal, dual) before its first interior-point iteration; index null or index[b] < 0: none.
+struct DevWarm {
+    const double *primal, *dual;
+    const int32_t *index;
+};
+
 // LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).  kc: entries per padded column of
 // the kernel's compile-time shape (Dims::kKC), 0 for the generic kernel; big: the generic kernel's streaming
 // form (lists and Riccati factor in global memory).

@@ -27,12 +27,15 @@
 struct FleetResult { // a solved node waiting to be consumed by the search (speculative expansion)
     double obj, nu_lb, nu_ub; // objective; multipliers of the two bounds of the next binary in time
     int32_t row;              // its row in the pools
+    bool vertex;              // optimal and polished: its record may be handed down to its children (hmpc_warm)
+    bool failed;              // the solver did not converge on it (MAXITER / NUMERICAL): an error IF the search consumes it
 };
 
 struct FleetTree {
     std::vector<int8_t> fix;   // n x nfix, -1 free / 0 / 1 (chronological prefixes)
     std::vector<double> lb;    // lower bound, +inf: proved infeasible
     std::vector<int32_t> row;  // dual row of the current pool the node carries (own if solved, else parent's), -1: none
+    std::vector<int32_t> wrow; // row of the parent's record (primal and dual pools of THIS step) to hand down, -1: none
     std::vector<uint8_t> alive;
     std::vector<int16_t> depth; // fixed binaries
     int n = 0;
@@ -59,15 +62,25 @@ struct hmpc_fleet {
     int8_t *d_fix = nullptr, *h_fix = nullptr, *d_fix_out = nullptr;
     double *d_x0 = nullptr, *h_x0 = nullptr, *d_obj = nullptr, *h_obj = nullptr, *d_primal = nullptr, *h_nu = nullptr;
     int32_t *d_status = nullptr, *h_status = nullptr, *d_iters = nullptr, *h_iters = nullptr;
-    int32_t *d_owner = nullptr, *h_owner = nullptr, *d_src = nullptr, *h_src = nullptr;
+    int32_t *d_owner = nullptr, *h_owner = nullptr, *d_src = nullptr, *h_src = nullptr, *d_widx = nullptr, *h_widx = nullptr;
+    int handdown = 1; // parent -> child hand-down of active sets (hmpc_fleet_options)
     double *d_lb = nullptr, *h_lb = nullptr, *d_lb_out = nullptr;
     uint8_t *d_flags = nullptr, *h_flags = nullptr;
     double *d_kx0 = nullptr, *d_ku0 = nullptr, *d_ke0 = nullptr, *h_k = nullptr; // K x nx, K x nu, K x nx (pinned: 3 blocks)
     double *h_prow = nullptr;                                                  // pinned: one primal row
-    long long rounds = 0, launched = 0;
+    long long rounds = 0, launched = 0, handed = 0;
+    bool broken = false; // a call failed midway: the trees are half updated until hmpc_fleet_reset(f, -1)
 };
 
 namespace {
+
+// An error in the middle of a step leaves some trees advanced and others not: the fleet refuses further steps until the
+// caller has reset it (hmpc_fleet_reset(f, -1)).
+int fleet_fail(hmpc_fleet *f, int code, const std::string &msg)
+{
+    f->broken = true;
+    return fail(code, msg + " -- the fleet must be reset (hmpc_fleet_reset(f, -1)) before it is used again");
+}
 
 template <class T> int dev_alloc(T **p, size_t n) { return hipMalloc((void **)p, (n ? n : 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
 template <class T> int pin_alloc(T **p, size_t n) { return hipHostMalloc((void **)p, (n ? n : 1) * sizeof(T), hipHostMallocDefault) == hipSuccess ? 0 : -1; }
@@ -75,15 +88,15 @@ template <class T> int pin_alloc(T **p, size_t n) { return hipHostMalloc((void *
 void fleet_free_round(hmpc_fleet *f)
 {
     for (void *d : {(void *)f->d_fix, (void *)f->d_fix_out, (void *)f->d_x0, (void *)f->d_obj, (void *)f->d_primal, (void *)f->d_status, (void *)f->d_iters,
-                    (void *)f->d_owner, (void *)f->d_src, (void *)f->d_lb, (void *)f->d_lb_out, (void *)f->d_flags})
+                    (void *)f->d_owner, (void *)f->d_src, (void *)f->d_widx, (void *)f->d_lb, (void *)f->d_lb_out, (void *)f->d_flags})
         if (d) (void)hipFree(d);
     for (void *d : {(void *)f->h_fix, (void *)f->h_x0, (void *)f->h_obj, (void *)f->h_nu, (void *)f->h_status, (void *)f->h_iters, (void *)f->h_owner,
-                    (void *)f->h_src, (void *)f->h_lb, (void *)f->h_flags})
+                    (void *)f->h_src, (void *)f->h_widx, (void *)f->h_lb, (void *)f->h_flags})
         if (d) (void)hipHostFree(d);
     f->d_fix = f->h_fix = f->d_fix_out = nullptr;
     f->d_x0 = f->h_x0 = f->d_obj = f->h_obj = f->d_primal = f->h_nu = nullptr;
     f->d_status = f->h_status = f->d_iters = f->h_iters = nullptr;
-    f->d_owner = f->h_owner = f->d_src = f->h_src = nullptr;
+    f->d_owner = f->h_owner = f->d_src = f->h_src = f->d_widx = f->h_widx = nullptr;
     f->d_lb = f->h_lb = f->d_lb_out = nullptr;
     f->d_flags = f->h_flags = nullptr;
     f->cap_b = 0;
@@ -103,6 +116,7 @@ int fleet_ensure_round(hmpc_fleet *f, size_t B)
     bad |= pin_alloc(&f->h_nu, cap * 2 * nfix);
     bad |= dev_alloc(&f->d_status, cap) | pin_alloc(&f->h_status, cap) | dev_alloc(&f->d_iters, cap) | pin_alloc(&f->h_iters, cap);
     bad |= dev_alloc(&f->d_owner, cap) | pin_alloc(&f->h_owner, cap) | dev_alloc(&f->d_src, cap) | pin_alloc(&f->h_src, cap);
+    bad |= dev_alloc(&f->d_widx, cap) | pin_alloc(&f->h_widx, cap);
     bad |= dev_alloc(&f->d_lb, cap) | pin_alloc(&f->h_lb, cap) | dev_alloc(&f->d_lb_out, cap);
     bad |= dev_alloc(&f->d_flags, cap) | pin_alloc(&f->h_flags, cap);
     if (bad) return fail(HMPC_EDEVICE, "fleet: cannot allocate the round buffers");
@@ -119,10 +133,18 @@ int fleet_ensure_rows(hmpc_fleet *f, size_t rows)
     const size_t cap = std::max<size_t>(rows + rows / 2, 4096);
     for (int s = 0; s < 2; s++) {
         double *np_ = nullptr, *nd = nullptr;
-        if (dev_alloc(&np_, cap * p.n_dual) || dev_alloc(&nd, cap)) return fail(HMPC_EDEVICE, "fleet: cannot grow the row pools");
+        if (dev_alloc(&np_, cap * p.n_dual) || dev_alloc(&nd, cap)) {
+            if (np_) (void)hipFree(np_);
+            if (nd) (void)hipFree(nd);
+            return fail(HMPC_EDEVICE, "fleet: cannot grow the row pools");
+        }
         if (s == f->cur && f->used) {
-            HIPCHK(hipMemcpy(np_, f->pool[s], f->used * p.n_dual * sizeof(double), hipMemcpyDeviceToDevice));
-            HIPCHK(hipMemcpy(nd, f->dobj[s], f->used * sizeof(double), hipMemcpyDeviceToDevice));
+            if (hipMemcpy(np_, f->pool[s], f->used * p.n_dual * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess ||
+                hipMemcpy(nd, f->dobj[s], f->used * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+                (void)hipFree(np_);
+                (void)hipFree(nd);
+                return fail(HMPC_EDEVICE, "fleet: cannot copy the row pools");
+            }
         }
         if (f->pool[s]) (void)hipFree(f->pool[s]);
         if (f->dobj[s]) (void)hipFree(f->dobj[s]);
@@ -132,7 +154,10 @@ int fleet_ensure_rows(hmpc_fleet *f, size_t rows)
     {
         double *pp = nullptr;
         if (dev_alloc(&pp, cap * p.n_primal)) return fail(HMPC_EDEVICE, "fleet: cannot grow the row pools");
-        if (f->ppool && f->used) HIPCHK(hipMemcpy(pp, f->ppool, f->used * p.n_primal * sizeof(double), hipMemcpyDeviceToDevice));
+        if (f->ppool && f->used && hipMemcpy(pp, f->ppool, f->used * p.n_primal * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess) {
+            (void)hipFree(pp);
+            return fail(HMPC_EDEVICE, "fleet: cannot copy the row pools");
+        }
         if (f->ppool) (void)hipFree(f->ppool);
         f->ppool = pp;
     }
@@ -145,6 +170,7 @@ void tree_reset_cold(FleetTree &t, int nfix)
     t.fix.assign(nfix, (int8_t)-1);
     t.lb.assign(1, -std::numeric_limits<double>::infinity());
     t.row.assign(1, -1);
+    t.wrow.assign(1, -1);
     t.alive.assign(1, 1);
     t.depth.assign(1, 0);
     t.n = 1;
@@ -200,6 +226,7 @@ extern "C" int hmpc_fleet_reset(hmpc_fleet *f, int32_t k)
     if (!f || k < -1 || k >= f->K) return fail(HMPC_EINVAL, "fleet: bad loop index");
     const int nfix = f->h->dp.T * f->h->dp.nub;
     for (int i = (k < 0 ? 0 : k); i < (k < 0 ? f->K : k + 1); i++) tree_reset_cold(f->trees[i], nfix);
+    if (k < 0) f->broken = false;
     return HMPC_OK;
 }
 
@@ -214,6 +241,8 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
 {
     g_err.clear();
     if (!f || !x0) return fail(HMPC_EINVAL, "fleet: null argument");
+    if (f->broken) return fail(HMPC_EINVAL, "fleet: an earlier call failed midway; reset the fleet (hmpc_fleet_reset(f, -1)) first");
+    struct Guard { hmpc_fleet *f; bool ok = false; ~Guard() { if (!ok) f->broken = true; } } guard{f};
     if (width < 1) width = 1;
     if (speculation < 0) speculation = 0;
     hmpc_handle *h = f->h;
@@ -254,6 +283,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
         launch.clear();
         size_t B = 0;
         int rc;
+        bool any_warm = false;
         for (int pass = 0; pass < 2; pass++) { // pass 0 counts, pass 1 fills the staging buffers
             if (pass == 1) {
                 if (B == 0) break;
@@ -277,6 +307,10 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                                 if (pass == 1) {
                                     std::memcpy(f->h_fix + b * nfix, row, nfix);
                                     std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
+                                    // hand-down: the picked node receives its parent's record (solved in an earlier
+                                    // round of this step); a speculative descendant's parent rides in this very launch
+                                    f->h_widx[b] = (s == 0 && f->handdown) ? t.wrow[i] : -1;
+                                    any_warm |= f->h_widx[b] >= 0;
                                     launch.push_back({k, depth});
                                 }
                                 b++;
@@ -300,7 +334,10 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             HIPCHK(hipMemcpyAsync(f->d_x0, f->h_x0, B * nx * sizeof(double), hipMemcpyHostToDevice, f->stream));
             double *rows = f->pool[f->cur] + f->used * p.n_dual;
             hmpc_result r{f->d_obj, f->dobj[f->cur] + f->used, f->d_status, f->d_iters, f->ppool + f->used * p.n_primal, rows};
-            if ((rc = hmpc_solve_batch_device(h, f->d_x0, nx, f->d_fix, (int32_t)B, &r, f->stream))) return rc;
+            // (the parents' rows lie below f->used, this launch writes from f->used on)
+            hmpc_warm hw{f->ppool, f->pool[f->cur], f->d_widx, (int32_t)f->used};
+            if (any_warm) HIPCHK(hipMemcpyAsync(f->d_widx, f->h_widx, B * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+            if ((rc = hmpc_solve_batch_device(h, f->d_x0, nx, f->d_fix, (int32_t)B, any_warm ? &hw : nullptr, &r, f->stream))) return rc;
             HIPCHK(hipMemcpyAsync(f->h_obj, f->d_obj, B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpyAsync(f->h_status, f->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpyAsync(f->h_iters, f->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
@@ -310,7 +347,6 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             f->rounds++;
             f->launched += (long long)B;
             for (size_t q = 0; q < B; q++) {
-                if (f->h_status[q] > 1) return fail(HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
                 if (f->h_iters[q] & HMPC_ITERS_WEAK) {
                     // infeasible, but the ray is no proof to tolerance: it prunes this node at this step only.  With a
                     // dual objective of -inf the shift reopens the leaf whatever the model error (controller.py:555-558).
@@ -319,7 +355,9 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                 }
                 const int d = launch[q].depth;
                 const double *nu_ = f->h_nu + q * 2 * nfix;
-                FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q)};
+                FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q),
+                              f->h_status[q] == HMPC_OPTIMAL && (f->h_iters[q] & HMPC_ITERS_POLISHED) != 0, f->h_status[q] > 1};
+                f->handed += (f->h_iters[q] & HMPC_ITERS_HANDED) != 0;
                 f->trees[launch[q].k].cache.emplace(key_of(f->h_fix + q * nfix, d), e);
             }
             f->used += B;
@@ -332,6 +370,9 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                 if (it == t.cache.end()) return fail(HMPC_EDEVICE, "fleet: a selected node has no result");
                 const FleetResult e = it->second;
                 t.cache.erase(it);
+                // (a speculative descendant that did not converge is an error only here, when the search gets to it: the
+                // result of a step does not depend on what rode along)
+                if (e.failed) return fleet_fail(f, HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
                 const double obj = e.obj;
                 t.solves++;
                 t.lb[i] = obj;
@@ -352,6 +393,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                         t.fix[c * nfix + d] = (int8_t)v;
                         t.lb.push_back(obj + (v == 1 ? e.nu_lb : e.nu_ub));
                         t.row.push_back(e.row);
+                        t.wrow.push_back(e.vertex ? e.row : -1);
                         t.alive.push_back(1);
                         t.depth.push_back((int16_t)(d + 1));
                         t.n++;
@@ -376,6 +418,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
         for (int j = 0; j < nx && x1; j++) x1[(size_t)k * nx + j] = ok ? t.primal[nx + j] : NAN;
         if (t.running && t.inc < 0) t.running = false; // infeasible MIQP: the loop ends here (statistical_analysis.py:99-108)
     }
+    guard.ok = true;
     return HMPC_OK;
 }
 
@@ -385,6 +428,8 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
 {
     g_err.clear();
     if (!f || !e0) return fail(HMPC_EINVAL, "fleet: null argument");
+    if (f->broken) return fail(HMPC_EINVAL, "fleet: an earlier call failed midway; reset the fleet (hmpc_fleet_reset(f, -1)) first");
+    struct Guard { hmpc_fleet *f; bool ok = false; ~Guard() { if (!ok) f->broken = true; } } guard{f};
     hmpc_handle *h = f->h;
     HIPCHK(hipSetDevice(h->device));
     const DevProb &p = h->dp;
@@ -409,7 +454,7 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
         }
         B += keep[k].size();
     }
-    if (B == 0) return HMPC_OK;
+    if (B == 0) { guard.ok = true; return HMPC_OK; }
     int rc = fleet_ensure_round(f, B);
     if (rc) return rc;
     if ((rc = fleet_ensure_rows(f, std::max(f->used, B)))) return rc;
@@ -468,6 +513,7 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
         t.fix = nfixv;
         t.lb = lb;
         t.row = row;
+        t.wrow.assign(n, -1); // (the records of the step that ends here are not handed down across the shift)
         t.depth = depth;
         t.alive.assign(n, 1);
         t.n = (int)n;
@@ -476,6 +522,7 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
     }
     f->cur = nxt;
     f->used = B;
+    guard.ok = true;
     return HMPC_OK;
 }
 
@@ -484,5 +531,13 @@ extern "C" int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *l
     if (!f) return fail(HMPC_EINVAL, "fleet: null");
     if (rounds) *rounds = f->rounds;
     if (launched) *launched = f->launched;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_fleet_handdown(hmpc_fleet *f, int32_t enable, int64_t *verified)
+{
+    if (!f) return fail(HMPC_EINVAL, "fleet: null");
+    if (enable >= 0) f->handdown = enable != 0;
+    if (verified) *verified = f->handed;
     return HMPC_OK;
 }

@@ -46,6 +46,8 @@
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
+#define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
+#define HMPC_POLISH_WARM_VMAX 1e-2 // a handed-down set whose point misses an inactive row by more is dropped at once
 #ifndef HMPC_KERNEL_ATTR
 #define HMPC_KERNEL_ATTR
 #endif
@@ -1644,7 +1646,7 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 // Returns status; tau and the iteration count through references.
 template <class D, int RS, class RM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  bool &polished_out, bool &weak_out, double *trace)
+                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -1671,6 +1673,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
     polished_out = false;
     weak_out = false;
+    handed_out = false;
     bool tried = false; // the polish has been tried (and failed) on the current iterate
     int attempts = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
@@ -1685,6 +1688,63 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     int level = 0; // penalty of the polish in progress: 0 first level; 1 second; 2 back at the first for the last digits
 #define HMPC_RHO_OF(level) ((level) == 1 ? HMPC_POLISH_RHO2 : HMPC_POLISH_RHO)
     double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
+    // PARENT -> CHILD HAND-DOWN (the reference hands the parent's simplex basis to the child: controller.py:260-264,
+    // subproblem_solution.py:37-43).  wprim / wdual: the parent's record.  Its active set -- the rows with a positive
+    // multiplier that still exist in this node -- is tried by the polish passes below BEFORE the first interior-point
+    // iteration, multipliers and proximal centre from the parent: a child whose optimum lies on the same set (the branch
+    // that fixes a binary where the relaxation had it) verifies after one factorisation and a few solves.  A set that does
+    // not verify within HMPC_POLISH_ROUNDS_WARM rounds, or misses a row by HMPC_POLISH_WARM_VMAX, is dropped and the cold
+    // start below runs untouched.  Same steps as oracle/hsde_qp.c.
+    bool warm_try = false;
+    if (wprim != nullptr && p.polish) {
+        const int nu = D::nu(p);
+        for (int o = lane; o < n; o += D::kNT) {
+            const int t = o / nz < T ? o / nz : T;
+            const int j = o - t * nz;
+            S.w[o] = j < nx ? wprim[t * nx + j] : wprim[(T + 1) * nx + t * nu + (j - nx)];
+        }
+        __syncthreads();
+        set_prescribed<D>(p, S, lane, 1.0);
+        __syncthreads();
+        const int o_mu = (T + 1) * nx, o_lb = o_mu + (T - 1) * p.nc + p.ncL, o_ub = o_lb + T * nub;
+        double wi = 0, zi = 0;
+        for (int o = lane; o < n; o += D::kNT) wi = fmax(wi, fabs(S.w[o]));
+        for (int o = lane; o < (T + 1) * nx; o += D::kNT) zi = fmax(zi, fabs(wdual[o]) * p.cs);
+        ROWS_BEGIN(k, rw)
+            double d = 0.0;
+            if (rm.active(p, S, k, rw)) {
+                int t, lr;
+                row_decode(p, rw.e, t, lr);
+                double zr; // the parent's multiplier of this row in the units of the scaled problem
+                if (lr < p.nc) zr = wdual[o_mu + t * p.nc + lr] * p.cs / p.reg.scale[lr];
+                else if (lr >= p.mreg) zr = wdual[o_mu + t * p.nc + p.nc + (lr - p.mreg)] * p.cs / p.sct[lr - p.mreg];
+                else if (lr < p.nc + nub) zr = wdual[o_lb + t * nub + (lr - p.nc)] * p.cs;
+                else zr = wdual[o_ub + t * nub + (lr - p.nc - nub)] * p.cs;
+                zi = fmax(zi, zr);
+                R.prod(k, rw.e) = 1.0; // the cold start's multiplier, for the way back
+                if (zr > 0.0) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr; }
+                else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w); }
+                R.D(k, rw.e) = d;
+            }
+            S.e[rw.e] = d;
+        ROWS_END
+        {
+            double v[2] = {wi, zi};
+            const int op[2] = {1, 1};
+            block_reduce<D, 2>(v, op, S.red, lane);
+            winf = v[0]; zinf = v[1];
+        }
+        if (winf == winf && zinf == zinf) { mode = 1; warm_try = true; }
+        else { // (a parent record that is not a finite point: nothing to hand down)
+            ROWS_BEGIN(k, rw)
+                if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = 1.0;
+            ROWS_END
+            for (int o = lane; o < n; o += D::kNT) S.w[o] = 0.0;
+            __syncthreads();
+            set_prescribed<D>(p, S, lane, tau);
+        }
+        __syncthreads();
+    }
     for (it = 0; it <= p.max_iter;) {
       if (mode == 0) {
         STAMP(7);
@@ -1940,6 +2000,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (mode != 0) {
             // ---------------- polish: multiplier step, verification, next pass ----------------
             int outcome = 0; // 0 give up, 1 verified, 2 next pass
+            const int max_rounds = warm_try ? HMPC_POLISH_ROUNDS_WARM : HMPC_POLISH_ROUNDS;
             if (mode != 3) {
                 double pinf = 0, pmove = 0;
                 ROWS_BEGIN(k, rw)
@@ -1990,14 +2051,17 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // verified; at the second level: the same active set once more at the first, from these
                             // multipliers (what is left to settle are the components that matter, of the size of the
                             // second level's rounding; the slow ones are in place)
-                            act = (level == 1 && round + 1 < HMPC_POLISH_ROUNDS) ? 2 : 0;
-                        } else if (round + 1 < HMPC_POLISH_ROUNDS) {
+                            act = (level == 1 && round + 1 < max_rounds) ? 2 : 0;
+                        } else if (warm_try && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
+                            // the handed-down set is not near this node's optimum (the node is infeasible, or fixing the
+                            // binary moved the solution): dropped after this one factorisation
+                        } else if (round + 1 < max_rounds) {
                             // Rows on the wrong side change sides, but only those within a factor two of the worst
                             // violation / the most negative multiplier (a missing active row drags others across their
                             // bounds; the next round shows which are real).
                             act = 1;
                         }
-                    } else if (level == 0 && pinf == pinf && round + 1 < HMPC_POLISH_ROUNDS) {
+                    } else if (level == 0 && pinf == pinf && round + 1 < max_rounds) {
                         // The multiplier steps contract by 1 / (1 + rho lambda), lambda the eigenvalues of C_A Phi^-1 C_A':
                         // active rows that nearly depend on each other do not settle at the first level.  They do at the
                         // second -- not the first choice: eps rho is no longer below the proximal weight there (1e-9 in the
@@ -2045,6 +2109,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 tau = 1.0;
                 status = HMPC_OPTIMAL;
                 polished_out = true;
+                handed_out = warm_try;
                 __syncthreads();
                 break;
             }
@@ -2053,6 +2118,15 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             ROWS_BEGIN(k, rw)
                 if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = R.prod(k, rw.e);
             ROWS_END
+            if (warm_try) { // the hand-down did not verify: back to the cold start (multipliers and slacks are at 1 again)
+                warm_try = false;
+                for (int o = lane; o < n; o += D::kNT) S.w[o] = 0.0;
+                __syncthreads();
+                set_prescribed<D>(p, S, lane, tau);
+                __syncthreads();
+                mode = 0;
+                continue;
+            }
             tried = true;
             mode = 0;
             continue;
@@ -2349,7 +2423,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
 template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW>
 __global__ void __launch_bounds__(NW * WAVE) HMPC_KERNEL_ATTR
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
-               const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace, const int32_t *__restrict__ order)
+               const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace, const int32_t *__restrict__ order, const DevWarm warm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int RS = KF + KB + KT;
@@ -2472,9 +2546,12 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
 #endif
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
-        bool polished = false, weak = false;
+        bool polished = false, weak = false, handed = false;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
+        const int wrow = warm.index ? warm.index[qp] : -1; // the parent's record, if one is handed down
+        const double *wprim = wrow >= 0 ? warm.primal + (size_t)wrow * p.n_primal : nullptr;
+        const double *wdual = wrow >= 0 ? warm.dual + (size_t)wrow * p.n_dual : nullptr;
         // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
         // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
         // is the node's optimum.  Otherwise solve again with every row.
@@ -2482,7 +2559,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, weak, tr ? tr + term_on * 64 * 8 : nullptr);
+            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -2507,7 +2584,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
         HMPC_CHK(status >= HMPC_OPTIMAL && status <= HMPC_NUMERICAL && tau > 0.0, 7);
 #endif
-        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0);
+        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0) | (handed ? HMPC_ITERS_HANDED : 0);
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
         slot = S.flag[1];
@@ -2568,7 +2645,7 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
 // nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries), with the
 // row slots of their horizons and 1 / 2 / 4 waves per node, and the generic run-time-sized kernel.
-typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *, const int32_t *);
+typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *, const int32_t *, const DevWarm);
 struct hmpc_kernel_choice {
     hmpc_kernel_t fn;
     int waves;

@@ -128,7 +128,9 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
         {
             const double *dL = d + o_mu + (T - 1) * nc;
             // (the first 64 entries of rho_T, x0, u0 travel with the first batch)
-            const double rv = d[o_rho + T * nq + min(lane, nqT - 1)], xv = x0g[min(lane, nx - 1)], uv = u0g[min(lane, nu - 1)];
+            // (nqT == 0 -- no terminal cost -- is legal: the clamp would then address entry -1, the last multiplier of the old
+            // last stage; the condition is wave uniform, so it adds no lane predicate)
+            const double rv = nqT > 0 ? d[o_rho + T * nq + min(lane, nqT - 1)] : 0.0, xv = x0g[min(lane, nx - 1)], uv = u0g[min(lane, nu - 1)];
             for (int k0 = 0; k0 < ncL; k0 += 64 * SHIFT_HEAD_SLOTS) {
                 double mh[SHIFT_HEAD_SLOTS];
 #pragma unroll
@@ -136,7 +138,8 @@ __global__ void __launch_bounds__(64 * SHIFT_WAVES) HMPC_SHIFT_ATTR hmpc_shift_k
 #pragma unroll
                 for (int u = 0; u < SHIFT_HEAD_SLOTS; u++) muL[min(k0 + u * 64 + lane, ncL - 1)] = mh[u];
             }
-            rhoT[min(lane, nqT - 1)] = rv; xs[min(lane, nx - 1)] = xv; us[min(lane, nu - 1)] = uv;
+            if (nqT > 0) rhoT[min(lane, nqT - 1)] = rv;
+            xs[min(lane, nx - 1)] = xv; us[min(lane, nu - 1)] = uv;
         }
         for (int k = lane + 64; k < nqT; k += 64) rhoT[k] = d[o_rho + T * nq + k];
         for (int j = lane + 64; j < nx; j += 64) xs[j] = x0g[j];

@@ -120,8 +120,8 @@ def branch_and_bound(
         Maximum number of candidates solved per round (1 = reference node order).
     incumbent_exchange : function (ub, n_candidates) -> (ub, n_candidates), optional
         Multi-GPU hook, called once per round by every rank: returns the minimum of the upper
-        bound and the total number of open candidates over all ranks (``distributed.py``).
-        The search ends when no rank has a candidate left.
+        bound over all ranks and the LARGEST number of open candidates on any rank
+        (``distributed.py``).  The search ends when no rank has a candidate left.
     speculation : function identifier -> list of identifiers, optional
         Speculative multi-level expansion (needs ``batch_solver``): descendants of a node that are
         solved in the same launch as the node itself, before it is known whether the search will

@@ -104,6 +104,9 @@ class HybridModelPredictiveController(object):
         self._update['rho'] = np.linalg.pinv(self.Q.T).dot(self.Q_T.T)
 
         self.solver_params = dict(solver_params or {})
+        # parent -> child hand-down of active sets in feedforward (the reference's optional simplex-basis hand-down,
+        # controller.py:260-264): off by default, as in the reference's published runs
+        self.handdown = bool(self.solver_params.pop('handdown', False))
         if backend is None:
             from .qp_backend import HipBatchedQP  # fails loudly without the HIP library / a GPU
             backend = HipBatchedQP(self.problem_data(), **self.solver_params)
@@ -176,18 +179,27 @@ class HybridModelPredictiveController(object):
     # QP relaxations
     # ------------------------------------------------------------------
 
-    def solve_frontier(self, identifiers, x0):
+    def solve_frontier(self, identifiers, x0, active_sets=None):
         """Solves the QP relaxations of many nodes in one batched call.
 
         identifiers : list of dict, or an int8 array (B, T*nub) with -1 = free
         x0 : (nx,) shared by all nodes, or (B, nx)
+        active_sets : optional list, per node the ``active_set`` of its parent's solution (what ``_brancher`` hands to a
+            child, controller.py:426) or None -- the parent -> child hand-down of ``hmpc_warm`` (include/hmpc.h)
         Returns (list of SubproblemSolution, solver wall time in seconds).
         """
         if isinstance(identifiers, np.ndarray):
             fix = np.ascontiguousarray(identifiers, dtype=np.int8)
         else:
             fix = np.stack([self._fix_vector(i) for i in identifiers])
-        res = self.qp.solve_batch(np.asarray(x0, dtype=np.float64), fix)
+        warm = None
+        if active_sets is not None and any(a is not None for a in active_sets):
+            rows = [a for a in active_sets if a is not None]
+            index = np.full(fix.shape[0], -1, dtype=np.int32)
+            index[[b for b, a in enumerate(active_sets) if a is not None]] = np.arange(len(rows), dtype=np.int32)
+            warm = (np.stack([a[0] for a in rows]), np.stack([a[1] for a in rows]), index)
+        res = (self.qp.solve_batch(np.asarray(x0, dtype=np.float64), fix, warm=warm) if warm is not None
+               else self.qp.solve_batch(np.asarray(x0, dtype=np.float64), fix))
         bad = np.flatnonzero(res['status'] > 1)
         if bad.size:
             # MAXITER / NUMERICAL nodes are surfaced, never silently treated as solved
@@ -198,6 +210,11 @@ class HybridModelPredictiveController(object):
                                              res['status'][b], res['primal'][b], res['dual'][b],
                                              weak=weak is not None and weak[b])
                 for b in range(fix.shape[0])]
+        # what a child of this node may be handed: the record of an optimal, polished (exactly complementary) node
+        polished = res.get('polished')
+        for b, sol in enumerate(sols):
+            if res['status'][b] == 0 and polished is not None and polished[b]:
+                sol.active_set = (res['primal'][b], res['dual'][b])
         return sols, res['time']
 
     def _solve_subproblem(self, identifier, x0, active_set=None):
@@ -217,7 +234,10 @@ class HybridModelPredictiveController(object):
         Solves the mixed integer program by branch and bound (controller.py:329-393).
 
         ``gurobi_params`` is accepted for drop-in compatibility and ignored
-        (there is no Gurobi); extra keyword arguments go to
+        (there is no Gurobi); ``handdown=True`` hands every parent's active set to
+        its children (the reference's optional simplex-basis hand-down,
+        controller.py:260-264 -- see ``hmpc_warm`` in include/hmpc.h; default: the
+        controller's ``solver_params['handdown']``, off); extra keyword arguments go to
         ``branch_and_bound`` (``tol``, ``warm_start``, ``printing_period``,
         ``frontier_width``, ``stats`` ...).  ``speculation_depth=k`` solves, together
         with every selected node, its descendants down to k more binaries
@@ -240,8 +260,11 @@ class HybridModelPredictiveController(object):
             solution, solve_time = self._solve_subproblem(identifier, x0)
             return unpack(solution, solve_time)
 
+        handdown = bool(kwargs.pop('handdown', self.handdown))
+
         def batch_solver(nodes, cutoff):
-            sols, t = self.solve_frontier([n.identifier for n in nodes], x0)
+            sets = [n.extra.active_set if n.extra is not None else None for n in nodes] if handdown else None
+            sols, t = self.solve_frontier([n.identifier for n in nodes], x0, active_sets=sets)
             return [unpack(s, t / len(sols)) for s in sols]
 
         def brancher(parent):

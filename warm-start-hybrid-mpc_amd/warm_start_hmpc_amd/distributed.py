@@ -38,19 +38,30 @@ class IncumbentExchange(object):
         self.torch, self.dist, self.group = torch, dist, group
         self.device = device if device is not None else 'cpu'
         self.rounds = 0
+        # Do the peers wait for a round from this rank?  Yes before the first round and after every round that ended with
+        # open candidates somewhere; no while a round is in progress (an error raised BY the exchange must not be answered
+        # with another collective) and after the round in which every rank reported none (all ranks have left the loop).
+        self.owed = True
 
     def __call__(self, ub, n_candidates):
         torch, dist = self.torch, self.dist
+        self.owed = False
         pair = torch.tensor([ub, -float(n_candidates)], dtype=torch.float64, device=self.device)
         dist.all_reduce(pair, op=dist.ReduceOp.MIN, group=self.group)
         self.rounds += 1
         ub_all, open_max = pair.tolist()          # (the search only asks whether ANY rank still has candidates)
         if ub_all == -np.inf:
             raise PeerFailure('the branch and bound of another rank failed')
+        self.owed = int(round(-open_max)) > 0
         return float(ub_all), int(round(-open_max))
 
     def abort(self):
-        """This rank's contribution to the round the others are waiting in, after its own search failed."""
+        """This rank's contribution to the round the others are waiting in, after its own search failed -- only if they
+        are: an error raised by the exchange itself, or after the last round, is not answered with a collective the peers
+        would never match."""
+        if not self.owed:
+            return
+        self.owed = False
         pair = self.torch.tensor([-np.inf, 0.], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(pair, op=self.dist.ReduceOp.MIN, group=self.group)
 

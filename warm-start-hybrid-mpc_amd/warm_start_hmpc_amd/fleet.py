@@ -15,7 +15,10 @@ import numpy as np
 
 class FleetMPC(object):
 
-    def __init__(self, controller, K):
+    def __init__(self, controller, K, handdown=True):
+        """handdown: children solved in a later round than their parent receive the parent's record (``hmpc_warm``: the
+        parent's active set is tried before the first interior-point iteration; the reference hands down the simplex
+        basis, controller.py:260-264)."""
         qp = controller.qp
         if not hasattr(qp, 'handle'):
             raise RuntimeError('FleetMPC needs the HIP backend (the product path has no CPU fallback).')
@@ -24,6 +27,7 @@ class FleetMPC(object):
         self.nx, self.nu = controller.mld.nx, controller.mld.nu
         self._f = ctypes.c_void_p()
         qp._check(qp.lib.hmpc_fleet_create(qp.handle, self.K, ctypes.byref(self._f)))
+        qp._check(qp.lib.hmpc_fleet_handdown(self._f, int(bool(handdown)), None))
 
     def __del__(self):
         f = getattr(self, '_f', None)
@@ -58,9 +62,10 @@ class FleetMPC(object):
         return cover, reopened
 
     def stats(self):
-        r, n = ctypes.c_int64(), ctypes.c_int64()
+        r, n, v = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self.qp._check(self.qp.lib.hmpc_fleet_stats(self._f, ctypes.byref(r), ctypes.byref(n)))
-        return dict(rounds=r.value, launched=n.value)
+        self.qp._check(self.qp.lib.hmpc_fleet_handdown(self._f, -1, ctypes.byref(v)))
+        return dict(rounds=r.value, launched=n.value, handed=v.value)
 
     def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0):
         """K closed loops from the same x0 under prescribed model errors (K, n_steps, nx) -- the shape of
@@ -89,7 +94,8 @@ class FleetMPC(object):
         return st
 
 
-def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, speculation=0, log=None, sim_ids=None):
+def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, speculation=0, log=None, sim_ids=None,
+                      handdown=True):
     """The reference's closed-loop study (``notebooks/cart_pole_with_walls/statistical_analysis.py:93-196``) on the fleet
     driver: K simulations in lockstep under prescribed model errors ``errors`` (K, n_steps, nx); at every step a
     cold-started search (a second fleet, reset before every step; ``cold_too``) and a warm-started one from the same
@@ -104,8 +110,8 @@ def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, s
     errors = np.asarray(errors, dtype=np.float64)
     K, n_steps = errors.shape[:2]
     sim_ids = list(range(K)) if sim_ids is None else list(sim_ids)
-    warm = FleetMPC(controller, K)
-    cold = FleetMPC(controller, K) if cold_too else None
+    warm = FleetMPC(controller, K, handdown=handdown)
+    cold = FleetMPC(controller, K, handdown=handdown) if cold_too else None
     xs = np.repeat(np.asarray(x0, dtype=np.float64)[None], K, axis=0)
     alive = np.ones(K, dtype=bool)
     st = dict(nodes_ws=[[] for _ in range(K)], nodes_cs=[[] for _ in range(K)], len_ws=[[] for _ in range(K)],
@@ -143,6 +149,7 @@ def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, s
         alive = ok
     wall = perf_counter() - tic
     st.update(wall=wall, steps=steps, steps_per_sec=steps / wall if wall > 0 else 0., survivors=int(alive.sum()),
+              handed=warm.stats()['handed'] + (cold.stats()['handed'] if cold else 0),
               rounds=warm.stats()['rounds'] + (cold.stats()['rounds'] if cold else 0),
               launched=warm.stats()['launched'] + (cold.stats()['launched'] if cold else 0))
     return st

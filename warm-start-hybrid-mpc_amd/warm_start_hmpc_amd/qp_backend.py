@@ -40,6 +40,10 @@ class _Result(ctypes.Structure):
                 ('iters', ctypes.c_void_p), ('primal', ctypes.c_void_p), ('dual', ctypes.c_void_p)]
 
 
+class _Warm(ctypes.Structure):
+    _fields_ = [('primal', ctypes.c_void_p), ('dual', ctypes.c_void_p), ('index', ctypes.c_void_p), ('rows', ctypes.c_int32)]
+
+
 class _ShiftMaps(ctypes.Structure):
     _fields_ = [('M_mu', _dp), ('M_rho', _dp), ('V', _dp)]
 
@@ -72,10 +76,10 @@ def load_library():
         lib.hmpc_launch_info.argtypes = [ctypes.c_void_p, _ip, _ip]
         lib.hmpc_solve_batch.restype = ctypes.c_int
         lib.hmpc_solve_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                         ctypes.c_int32, ctypes.POINTER(_Result)]
+                                         ctypes.c_int32, ctypes.POINTER(_Warm), ctypes.POINTER(_Result)]
         lib.hmpc_solve_batch_device.restype = ctypes.c_int
         lib.hmpc_solve_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
-                                                ctypes.c_int32, ctypes.POINTER(_Result), ctypes.c_void_p]
+                                                ctypes.c_int32, ctypes.POINTER(_Warm), ctypes.POINTER(_Result), ctypes.c_void_p]
         lib.hmpc_last_error.restype = ctypes.c_char_p
         lib.hmpc_set_shift_maps.restype = ctypes.c_int
         lib.hmpc_set_shift_maps.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ShiftMaps)]
@@ -95,12 +99,17 @@ def load_library():
         lib.hmpc_fleet_shift.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.hmpc_fleet_stats.restype = ctypes.c_int
         lib.hmpc_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.hmpc_fleet_handdown.restype = ctypes.c_int
+        lib.hmpc_fleet_handdown.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
         lib.hmpc_comm_unique_id.restype = ctypes.c_int
         lib.hmpc_comm_unique_id.argtypes = [ctypes.c_void_p]
         lib.hmpc_comm_create.restype = ctypes.c_int
         lib.hmpc_comm_create.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.hmpc_allreduce_incumbent.restype = ctypes.c_int
         lib.hmpc_allreduce_incumbent.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]
+        lib.hmpc_publish_incumbent.restype = ctypes.c_int
+        lib.hmpc_publish_incumbent.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_int32,
+                                               ctypes.POINTER(ctypes.c_int32)]
         lib.hmpc_comm_destroy.restype = ctypes.c_int
         lib.hmpc_comm_destroy.argtypes = [ctypes.c_void_p]
         lib.hmpc_lp_solve_batch.restype = ctypes.c_int
@@ -115,7 +124,7 @@ EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_la
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_comm_destroy',
+                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
 
 
@@ -210,10 +219,12 @@ class HipBatchedQP(object):
         """The facet LPs of the offline ingredients on this backend's device (see module-level ``lp_solve_batch``)."""
         return lp_solve_batch(A, c, b, relax=relax, device=self.device, **kw)
 
-    def solve_batch(self, x0, fix, want_primal=True, want_dual=True):
+    def solve_batch(self, x0, fix, want_primal=True, want_dual=True, warm=None):
         """Host arrays in, host arrays out (copies included in ``time``).
 
         x0 : (nx,) shared or (B, nx); fix : int8 (B, T*nub), -1 free / 0 / 1
+        warm : optional (primal rows, dual rows, index) -- the parent -> child hand-down of ``hmpc_warm``: node b tries
+            the active set of the record in row ``index[b]`` of the two arrays (-1: none) before its first iteration
         """
         fix = np.ascontiguousarray(fix, dtype=np.int8)
         if fix.ndim != 2 or fix.shape[1] != self.nfix:
@@ -231,19 +242,29 @@ class HipBatchedQP(object):
                    primal=np.empty((B, self.n_primal)) if want_primal else None,
                    dual=np.empty((B, self.n_dual)) if want_dual else None)
         res = _Result(**{k: (v.ctypes.data if v is not None else None) for k, v in out.items()})
+        w = None
+        if warm is not None:
+            wp = np.ascontiguousarray(warm[0], dtype=np.float64).reshape(-1, self.n_primal)
+            wd = np.ascontiguousarray(warm[1], dtype=np.float64).reshape(-1, self.n_dual)
+            wi = np.ascontiguousarray(warm[2], dtype=np.int32)
+            if wi.shape != (B,) or wp.shape[0] != wd.shape[0] or wi.max(initial=-1) >= wp.shape[0]:
+                raise ValueError('warm: need (rows x n_primal, rows x n_dual, index of length B into the rows).')
+            w = ctypes.byref(_Warm(wp.ctypes.data, wd.ctypes.data, wi.ctypes.data, wp.shape[0]))
         tic = time.perf_counter()
-        self._check(self.lib.hmpc_solve_batch(self.handle, x0.ctypes.data, stride, fix.ctypes.data, B, ctypes.byref(res)))
+        self._check(self.lib.hmpc_solve_batch(self.handle, x0.ctypes.data, stride, fix.ctypes.data, B, w, ctypes.byref(res)))
         out['time'] = time.perf_counter() - tic
+        out['handed'] = (out['iters'] >> 18) & 1        # HMPC_ITERS_HANDED: the active set handed down by the parent verified
         out['polished'] = (out['iters'] >> 16) & 1      # HMPC_ITERS_POLISHED
         out['weak'] = (out['iters'] >> 17) & 1          # HMPC_ITERS_WEAK: infeasible, the ray is no proof to tolerance
         out['iters'] = out['iters'] & 0xFFFF
         return out
 
-    def solve_batch_device(self, x0, fix, out, stream=None):
+    def solve_batch_device(self, x0, fix, out, stream=None, warm=None):
         """Device-resident form: torch CUDA tensors in and out, asynchronous on ``stream``
         (default: torch's current stream).  ``out`` is a dict of preallocated tensors with keys
         obj, dual_obj (float64 [B]), status, iters (int32 [B]), primal [B, n_primal], dual [B, n_dual]
-        (the last two may be None)."""
+        (the last two may be None).  ``warm``: optional (primal rows, dual rows, int32 index [B]) CUDA tensors, the
+        hand-down of ``hmpc_warm`` (the rows must not be rows of ``out``)."""
         import torch
         B = fix.shape[0]
         assert fix.dtype == torch.int8 and fix.is_cuda and fix.is_contiguous() and fix.shape[1] == self.nfix
@@ -253,7 +274,14 @@ class HipBatchedQP(object):
                          for k in ('obj', 'dual_obj', 'status', 'iters', 'primal', 'dual')})
         if stream is None:
             stream = torch.cuda.current_stream().cuda_stream
-        self._check(self.lib.hmpc_solve_batch_device(self.handle, x0.data_ptr(), stride, fix.data_ptr(), B,
+        w = None
+        if warm is not None:
+            wp, wd, wi = warm
+            assert wp.is_cuda and wd.is_cuda and wi.is_cuda and wp.is_contiguous() and wd.is_contiguous() and wi.is_contiguous()
+            assert wp.dtype == torch.float64 and wd.dtype == torch.float64 and wi.dtype == torch.int32 and wi.shape == (B,)
+            assert wp.shape[1] == self.n_primal and wd.shape[1] == self.n_dual and wp.shape[0] == wd.shape[0]
+            w = ctypes.byref(_Warm(wp.data_ptr(), wd.data_ptr(), wi.data_ptr(), wp.shape[0]))
+        self._check(self.lib.hmpc_solve_batch_device(self.handle, x0.data_ptr(), stride, fix.data_ptr(), B, w,
                                                      ctypes.byref(res), ctypes.c_void_p(stream)))
 
     def launch_info(self):
