@@ -41,9 +41,9 @@ def _replay_case(tr, name, backend, exact):
         order = []
         inner = ctrl.solve_frontier
 
-        def recording(identifiers, x0, _inner=inner):
+        def recording(identifiers, x0, _inner=inner, **kw):
             order.extend(ctrl._fix_vector(i) for i in identifiers)
-            return _inner(identifiers, x0)
+            return _inner(identifiers, x0, **kw)
 
         ctrl.solve_frontier = recording
         try:

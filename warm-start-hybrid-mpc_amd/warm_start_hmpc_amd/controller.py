@@ -263,8 +263,11 @@ class HybridModelPredictiveController(object):
         handdown = bool(kwargs.pop('handdown', self.handdown))
 
         def batch_solver(nodes, cutoff):
-            sets = [n.extra.active_set if n.extra is not None else None for n in nodes] if handdown else None
-            sols, t = self.solve_frontier([n.identifier for n in nodes], x0, active_sets=sets)
+            if handdown:
+                sets = [n.extra.active_set if n.extra is not None else None for n in nodes]
+                sols, t = self.solve_frontier([n.identifier for n in nodes], x0, active_sets=sets)
+            else:
+                sols, t = self.solve_frontier([n.identifier for n in nodes], x0)
             return [unpack(s, t / len(sols)) for s in sols]
 
         def brancher(parent):
