@@ -339,19 +339,35 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
             'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
             'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
         del fl
+    # (e) the same 1024 loops as several fleets, each on its own handle and host thread: the kernel of one fleet overlaps
+    # the host bookkeeping of the others (fleet.closed_loop_parallel)
+    from warm_start_hmpc_amd.fleet import closed_loop_parallel
+    K = 1024
+    errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
+    for parts in (2, 4):
+        closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 2, errs[:, :2], parts=parts, frontier_width=8)           # warm-up
+        cold = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 1, errs[:, :1], parts=parts, frontier_width=8)
+        st = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), steps + 1, errs, parts=parts, frontier_width=8)
+        dt = st['wall'] - cold['wall']
+        out['fleet_1024_loops_%d_handles' % parts] = {
+            'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
+            'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'handdown': True,
+            'launches_per_step_incl_cold_mean': st['rounds'] / (steps + 1.0) / parts,
+            'driver': '%d fleets of %d loops, one handle and one host thread each (fleet.closed_loop_parallel)' % (parts, K // parts)}
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
 
 
-def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05):
+def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05, x_center=None):
     """B nodes of real branch-and-bound trees: cold-started searches from x0 = [0, 0, 1, 0] + spread * N(0, 1) * x_max
     (seed: rank, tree), every node they solve plus their leaves, until B nodes are collected.  Returns (x0 [B, nx],
     fix [B, T nub], parent [B]: row of the node's parent in this frontier or -1)."""
+    x_center = np.array([0., 0., 1., 0.]) if x_center is None else np.asarray(x_center, dtype=np.float64)
     from helpers import real_tree_with_parents
     xs, fixes, parents, n, j = [], [], [], 0, 0
     while n < B:
         rng = np.random.RandomState(7919 * rank + j)
-        x0 = np.array([0., 0., 1., 0.]) + (spread * rng.randn(4) * x_max if (rank or j) else 0.)
+        x0 = x_center + (spread * rng.randn(4) * x_max if (rank or j) else 0.)
         j += 1
         fix, parent = real_tree_with_parents(ctrl, x0, leaves_too=True, frontier_width=8)
         if not len(fix):

@@ -950,7 +950,7 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
                 if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)))
                     st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
             } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
-            status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol;
+            status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol | ((it2 > 0 || (ncL > nc && lazy_terminal && pol >= 0 && tv >= 0.0 && st == ST_OPTIMAL)) ? 0x200 : 0);
         }
         work_free(k);
     }

@@ -100,5 +100,6 @@ class OracleBatchedQP(object):
             raise RuntimeError('oracle_solve_batch failed with code %d' % rc)
         out['time'] = time.perf_counter() - tic
         out['weak'] = (out['polished'] >> 8) & 1        # infeasible, but the ray is no proof to tolerance (HMPC_ITERS_WEAK)
+        out['second'] = (out['polished'] >> 9) & 1      # the terminal-set rows were needed: the node was solved twice (lazy terminal set)
         out['polished'] &= 0xff
         return out

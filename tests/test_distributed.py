@@ -154,3 +154,51 @@ def test_monte_carlo_shards_simulations_over_ranks(tmp_path):
         b = np.load(os.path.join(two, '%s_sd_0.003.npy' % key))
         assert a.shape == (3, 3) and np.array_equal(a, b), key
     assert os.path.exists(os.path.join(two, 'solve_log_sd_0.003.rank1.log'))
+
+
+def _strong_scaling_worker(rank, world, port, q):
+    # bench.py --gpus N --frontier-total 256 (BASELINE configs[2] as specified: ONE frontier split over the ranks, node k
+    # to rank k mod N, one MIN all-reduce of the incumbent per step), rehearsed with the oracle backend under gloo: the
+    # frontier construction and the sharding are bench.py's own functions
+    for p in (ROOT, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    from helpers import make_controller, load_fixture
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle', threads=2)
+    x0_all, fix_all, _ = bench.real_tree_frontier(ctrl, 256, 0, load_fixture('cart_pole_with_walls')['x_max'], x_center=np.array([0., 0., .5, 0.]))
+    mine = bench.shard(256, world, rank)
+    res = ctrl.qp.solve_batch(np.ascontiguousarray(x0_all[mine]), np.ascontiguousarray(fix_all[mine]))
+    full = (fix_all[mine] >= 0).all(axis=1) & (res['status'] == 0)
+    ub = torch.tensor([res['obj'][full].min() if full.any() else np.inf], dtype=torch.float64)
+    dist.all_reduce(ub, op=dist.ReduceOp.MIN)
+    q.put((rank, mine.tolist(), res['obj'].tolist(), float(ub.item())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_frontier_of_the_bench_under_gloo():
+    import bench
+    from helpers import make_controller, load_fixture
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_strong_scaling_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle', threads=4)
+    x0_all, fix_all, _ = bench.real_tree_frontier(ctrl, 256, 0, load_fixture('cart_pole_with_walls')['x_max'], x_center=np.array([0., 0., .5, 0.]))
+    ref = ctrl.qp.solve_batch(x0_all, fix_all)
+    merged = np.full(256, np.nan)
+    for _, idx, obj, _ in got:
+        assert np.all(np.isnan(merged[idx]))                            # disjoint shards ...
+        merged[idx] = obj
+    assert np.array_equal(merged, ref['obj'])                           # ... that cover the frontier; same records
+    full = (fix_all >= 0).all(axis=1) & (ref['status'] == 0)
+    assert got[0][3] == got[1][3] == ref['obj'][full].min()             # the same global incumbent on both ranks

@@ -1,5 +1,7 @@
 """The C++ fleet driver (hmpc_fleet_*, csrc/hmpc_fleet.hip: K closed loops in lockstep, trees behind the handle, multiplier
 rows resident in HBM) against the numpy lockstep driver (batched.BatchedMPC) and the reference's published runs."""
+import os
+
 import numpy as np
 import pytest
 
@@ -97,3 +99,47 @@ def test_incumbent_allreduce_through_the_c_abi():
     assert ub.value == float('inf') and n_open.value == 0
     assert lib.hmpc_comm_create(h, 2, 5, uid, ctypes.byref(ctypes.c_void_p())) == -1      # rank out of range
     assert lib.hmpc_comm_destroy(comm) == 0
+
+
+def test_incumbent_exchange_over_rccl_between_two_gpus(tmp_path):
+    # Two FRESH processes, one per GPU, communicator from hmpc_comm_unique_id: MIN semantics, the -inf abort path, owner and
+    # broadcast of the winning assignment over real RCCL (tests/rccl_two_ranks.py).  Needs two GPUs: on the one-GPU boxes of
+    # this pool it skips -- the N-rank path is then covered by the gloo tests (test_distributed.py) and the one-rank RCCL
+    # test above only.
+    import json
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (this box has %d): RCCL between ranks is not exercised here' % torch.cuda.device_count())
+    here = os.path.dirname(os.path.abspath(__file__))
+    ident = str(tmp_path / 'rccl_id')
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, 'rccl_two_ranks.py'), str(r), '2', ident],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    seen = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
+    for s in seen:
+        assert s['min'] == [2.0, 5]                                     # smallest bound, largest number of open candidates
+        assert s['abort'][0] == '-Infinity' or s['abort'][0] == float('-inf')
+        assert s['publish'][0] == 2.0 and s['publish'][1] == 1 and s['publish'][2] == [1] * 40
+        assert s['tie'][0] == 1.0 and s['tie'][1] == 0 and s['tie'][2] == [10] * 40
+        assert s['none'][1] == -1
+        assert s['root_status'] == 0
+
+
+def test_incumbent_publication_over_rccl_with_one_rank(tmp_path):
+    # the same script as the two-GPU test with a communicator of one rank: every entry point of the exchange goes through
+    # RCCL on this box (all-reduce, all-reduce of the owner, broadcast), in a fresh process
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, 'rccl_two_ranks.py'), '0', '1', str(tmp_path / 'rccl_id')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = json.loads(r.stdout.strip().splitlines()[-1])
+    assert s['min'] == [3.0, 5] and s['abort'][0] == float('-inf')
+    assert s['publish'][:2] == [2.5, 0] and s['publish'][2] == [0] * 40
+    assert s['tie'][:2] == [1.0, 0] and s['none'][1] == -1 and s['root_status'] == 0

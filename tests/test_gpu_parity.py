@@ -27,7 +27,7 @@ ETOL, EFLOOR = 1e-5, 1e-6   # element-wise: every component within 1e-5 of its o
 WORST = {'norm': 0.0, 'element': 0.0, 'dense': 0.0}   # largest deviations seen in this session (printed at the end)
 
 
-def _rel(a, b):
+def _rel(a, b, elementwise=True):
     """Largest deviation of a from b per row, relative to the row's largest entry of b (floor 1e-2) -- and, beside
     that norm-wise measure, the element-wise one: every component relative to its OWN size (floor EFLOOR), so that a
     small component (a pole angle of 1e-3 next to a velocity of 1) is held to the same relative accuracy."""
@@ -35,8 +35,11 @@ def _rel(a, b):
         return np.zeros(a.shape[0])
     scale = np.maximum(1e-2, np.max(np.abs(b), axis=1, keepdims=True))
     norm = np.max(np.abs(a - b) / scale, axis=1)
+    WORST['norm'] = max(WORST['norm'], norm.max())
+    if not elementwise:
+        return norm
     elem = np.max(np.abs(a - b) / np.maximum(np.abs(b), EFLOOR), axis=1)
-    WORST['norm'], WORST['element'] = max(WORST['norm'], norm.max()), max(WORST['element'], elem.max())
+    WORST['element'] = max(WORST['element'], elem.max())
     return np.maximum(norm, elem * (RTOL / ETOL))
 
 
@@ -76,20 +79,22 @@ def _dense_check(ctrl, T, x0, fix, rec, sample=64, seed=0):
     return opt.size
 
 
-def _trajectories_close(ctrl, T, fix, pa, pb, what=''):
+def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True):
     """States, the inputs the cost is strictly convex in (unique at every node), and -- where every binary is
     fixed, the nodes an incumbent comes from -- ALL inputs, at RTOL.  Inputs no cost term sees are not unique in
     a relaxation: a vertex solution and Gurobi's would differ there as well."""
     nx, nu = ctrl.mld.nx, ctrl.mld.nu
     xa, xb = pa[:, :(T + 1) * nx], pb[:, :(T + 1) * nx]
     ua, ub = pa[:, (T + 1) * nx:].reshape(-1, T, nu), pb[:, (T + 1) * nx:].reshape(-1, T, nu)
-    assert _rel(xa, xb).max(initial=0) < RTOL, (what, 'x', _rel(xa, xb).max())
+    # (element-wise -- every component to 1e-5 of its own size -- where both sides return the vertex of an active set;
+    # an interior-point iterate that meets the stopping test is compared norm-wise only)
+    assert _rel(xa, xb, elementwise).max(initial=0) < RTOL, (what, 'x', _rel(xa, xb, elementwise).max())
     for j in determined_inputs(ctrl):
-        assert _rel(ua[:, :, j], ub[:, :, j]).max(initial=0) < RTOL, (what, 'u', j, _rel(ua[:, :, j], ub[:, :, j]).max())
+        assert _rel(ua[:, :, j], ub[:, :, j], elementwise).max(initial=0) < RTOL, (what, 'u', j, _rel(ua[:, :, j], ub[:, :, j], elementwise).max())
     if fix is not None:
         full = (np.asarray(fix) >= 0).all(axis=1)
         if full.any():
-            assert _rel(ua[full].reshape(full.sum(), -1), ub[full].reshape(full.sum(), -1)).max() < RTOL, (what, 'u of fully fixed nodes')
+            assert _rel(ua[full].reshape(full.sum(), -1), ub[full].reshape(full.sum(), -1), elementwise).max() < RTOL, (what, 'u of fully fixed nodes')
 
 
 def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
@@ -111,7 +116,8 @@ def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
     np.testing.assert_allclose(a['dual_obj'][raw], b['dual_obj'][raw], rtol=2e-6, atol=1e-9)
     if min_polished is not None:
         assert pol.sum() >= min_polished * fin.sum(), (pol.sum(), fin.sum())
-    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[fin], a['primal'][fin], b['primal'][fin])
+    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[pol], a['primal'][pol], b['primal'][pol], 'polished')
+    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[raw], a['primal'][raw], b['primal'][raw], 'iterate', elementwise=False)
     inf = a['status'] == 1
     assert np.all(np.isinf(a['obj'][inf])) and np.all(np.isnan(a['primal'][inf]))
     # Farkas rays are normalised to a unit largest multiplier on both sides

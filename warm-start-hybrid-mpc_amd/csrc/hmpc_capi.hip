@@ -331,7 +331,8 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
             hmpc_destroy(h);
             return fail(HMPC_ETOOBIG, msg);
         }
-        if (hipFuncSetAttribute((const void *)cf.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess) {
+        if (hipFuncSetAttribute((const void *)cf.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)cf.k.fn_warm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess) {
             hmpc_destroy(h);
             return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
         }
@@ -556,7 +557,7 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
         order = h->order;
         hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order);
     }
-    hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
+    hipLaunchKernelGGL(w.index ? k.fn_warm : k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order, w);
     HIPCHK(hipGetLastError());
     return HMPC_OK;

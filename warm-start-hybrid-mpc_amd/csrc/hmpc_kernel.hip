@@ -454,18 +454,73 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
         a = col_dot(stage_lists<D>(S), j, base + t * p.mreg);
     }
     if (S.term_on && t == p.T - 1) {
-        const int nz = D::nz(p);
-        const ldsd *vt = base + p.Toff;
-        double a0 = 0, a1 = 0;
-        int k = 0;
-        for (; k + 2 <= p.nT; k += 2) {
-            a0 += p.Ct[(size_t)k * nz + j] * vt[k];
-            a1 += p.Ct[(size_t)(k + 1) * nz + j] * vt[k + 1];
+        if constexpr (D::kKC > 0) {
+            a += S.mv[j]; // the terminal rows' part, reduced over the rows' owners beforehand (term_cols)
+        } else {
+            const int nz = D::nz(p);
+            const ldsd *vt = base + p.Toff;
+            double a0 = 0, a1 = 0;
+            int k = 0;
+            for (; k + 2 <= p.nT; k += 2) {
+                a0 += p.Ct[(size_t)k * nz + j] * vt[k];
+                a1 += p.Ct[(size_t)(k + 1) * nz + j] * vt[k + 1];
+            }
+            if (k < p.nT) a0 += p.Ct[(size_t)k * nz + j] * vt[k];
+            a += a0 + a1;
         }
-        if (k < p.nT) a0 += p.Ct[(size_t)k * nz + j] * vt[k];
-        a += a0 + a1;
     }
     return a;
+}
+
+// Terminal-set part of C' v for the compile-time shapes: (C_T' v_T)(j), j < nz, into S.mv, for the ccol_dot calls
+// that follow.  The terminal rows are dense and stay in global memory (L1 / L2 resident, the same for every node).  As a
+// loop over the rows inside ccol_dot -- run by the eleven lanes that hold a component of the last stage while the rest
+// of the wave waits -- the ~100 dependent global loads cost more than the whole rest of a solve: a node that needs the
+// terminal set (lazy terminal set: a second solve) ran four times slower per iteration, and with closed-loop states --
+// 6 % of the nodes of real trees -- those nodes set the makespan of a launch.  Here every lane takes the rows it owns
+// in the row map's terminal slots (its loads are independent and in flight together) and the products are reduced over
+// the workgroup.  `base` as in ccol_dot.  Must be called by all threads; ends with a barrier.
+template <class D, class RM> DEV void term_cols(const DevProb &p, const Lds &S, int lane, const ldsd *base)
+{
+    if constexpr (D::kKC > 0) {
+        if (!S.term_on) return;
+        constexpr int NZ = D::kNX + D::kNU, KT = RM::kSlots - RM::kSlotsFB;
+        double acc[NZ];
+#pragma unroll
+        for (int j = 0; j < NZ; j++) acc[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < KT; k++) {
+            const int row = k * D::kNT + lane;
+            const bool ok = row < p.nT;
+            const int rc = ok ? row : 0; // (clamped: a load under a lane predicate waits for itself)
+            const double v = ok ? base[p.Toff + rc] : 0.0;
+            const double *c = p.Ct + (size_t)rc * NZ;
+#pragma unroll
+            for (int j = 0; j < NZ; j++) acc[j] += c[j] * v;
+        }
+        if constexpr (D::kNW == 1) {
+#pragma unroll
+            for (int j = 0; j < NZ; j++) acc[j] = wave_sum(acc[j]);
+        } else {
+            constexpr int CH = 40 / D::kNW; // block_reduce exchanges kNW * N values through S.red (40 doubles)
+#pragma unroll
+            for (int j0 = 0; j0 < NZ; j0 += CH) {
+                double v[CH];
+                int op[CH];
+#pragma unroll
+                for (int q = 0; q < CH; q++) { v[q] = j0 + q < NZ ? acc[j0 + q] : 0.0; op[q] = 0; }
+                block_reduce<D, CH>(v, op, S.red, lane);
+#pragma unroll
+                for (int q = 0; q < CH; q++)
+                    if (j0 + q < NZ) acc[j0 + q] = v[q];
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NZ; j++) S.mv[j] = acc[j];
+        }
+        __syncthreads();
+    }
 }
 template <class D> DEV double hrow(const DevProb &p, const Lds &S, int lr) { return lr < p.mreg ? stage_lists<D>(S).h[lr] : p.ht[lr - p.mreg]; }
 // ---------------------------------------------------------------------------------------------
@@ -921,18 +976,31 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             S.Mm[j * NZ + i] = a;
         }
         if (S.term_on) {
-            for (int q = lane; q < NE; q += WAVE) {
-                const int i = S.ei[q], j = S.ej[q];
-                const ldsd *Dt = S.e + p.Toff;
-                double a0 = 0, a1 = 0;
-                int k = 0;
-                for (; k + 2 <= p.nT; k += 2) {
-                    a0 += p.Ct[(size_t)k * NZ + i] * p.Ct[(size_t)k * NZ + j] * Dt[k];
-                    a1 += p.Ct[(size_t)(k + 1) * NZ + i] * p.Ct[(size_t)(k + 1) * NZ + j] * Dt[k + 1];
+            // dense terminal block C_T' D C_T: every lane takes terminal rows lane, lane + 64, ... (coefficients in
+            // registers for the moment, loads independent), every entry is one sum over the wave -- as a loop over the
+            // ~100 rows per entry (three dependent loads a term) this block took longer than the rest of the factorisation
+            const ldsd *Dt = S.e + p.Toff;
+            for (int r0 = 0; r0 < p.nT; r0 += WAVE) { // (two trips for the cart-pole's 102 facets)
+                const int row = r0 + lane;
+                const bool ok = row < p.nT;
+                const int rc = ok ? row : 0;
+                const double dr = ok ? Dt[rc] : 0.0;
+                const double *c = p.Ct + (size_t)rc * NZ;
+                double cr[NZ];
+#pragma unroll
+                for (int j = 0; j < NZ; j++) cr[j] = c[j];
+#pragma unroll
+                for (int i = 0; i < NZ; i++) {
+#pragma unroll
+                    for (int j = 0; j <= i; j++) {
+                        const double a = wave_sum(cr[i] * cr[j] * dr);
+                        if (lane == 0) {
+                            const double v = (r0 ? TG[i * NZ + j] : 0.0) + a;
+                            TG[i * NZ + j] = v;
+                            TG[j * NZ + i] = v;
+                        }
+                    }
                 }
-                if (k < p.nT) a0 += p.Ct[(size_t)k * NZ + i] * p.Ct[(size_t)k * NZ + j] * Dt[k];
-                TG[i * NZ + j] = a0 + a1;
-                TG[j * NZ + i] = a0 + a1;
             }
         }
         double ABc[NX], pn[NX];
@@ -1386,6 +1454,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
     FSTAMP_DECL;
     LANE_OPAQUE(lane);
     // S.g <- (mb if useb) - (rhs_d + C' e): the part of the stage gradient the recursion does not touch
+    term_cols<D, RM>(p, S, lane, S.e);
     for (int o = lane; o < T * NZ; o += D::kNT) {
         const int t = o / NZ, j = o - t * NZ;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
@@ -1575,6 +1644,7 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
     __syncthreads();
     // multipliers of the fixed binaries from the stationarity row of their component
     const bool own_g = gsrc && gsrc != S.g;
+    term_cols<D, RM>(p, S, lane, S.e);
     for (int o = lane; o < T * NUB; o += D::kNT) {
         const int t = o / NUB, b = o - t * NUB;
         double a = 0;
@@ -1644,7 +1714,10 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 
 // One interior-point solve of the node with / without the terminal-set rows.
 // Returns status; tau and the iteration count through references.
-template <class D, int RS, class RM>
+// WARM: the instantiation that accepts a parent's record (hmpc_warm).  The cold kernels are compiled without any of it:
+// the hand-down code in front of the main loop costs the loop registers (scratch 116 -> 140 B per lane, 8 % on every
+// launch, measured) -- a launch without hand-down runs the kernel it always ran.
+template <class D, int RS, class RM, bool WARM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
                   bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual)
 {
@@ -1696,7 +1769,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // not verify within HMPC_POLISH_ROUNDS_WARM rounds, or misses a row by HMPC_POLISH_WARM_VMAX, is dropped and the cold
     // start below runs untouched.  Same steps as oracle/hsde_qp.c.
     bool warm_try = false;
-    if (wprim != nullptr && p.polish) {
+    if constexpr (WARM) if (wprim != nullptr && p.polish) {
         const int nu = D::nu(p);
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
@@ -1765,6 +1838,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         }
         double rdinf = 0, certinf = 0, fy = 0, yinf = 0;
         winf = 0;
+        term_cols<D, RM>(p, S, lane, S.e);
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
             const int j = o - t * nz;
@@ -2000,7 +2074,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (mode != 0) {
             // ---------------- polish: multiplier step, verification, next pass ----------------
             int outcome = 0; // 0 give up, 1 verified, 2 next pass
-            const int max_rounds = warm_try ? HMPC_POLISH_ROUNDS_WARM : HMPC_POLISH_ROUNDS;
+            const int max_rounds = (WARM && warm_try) ? HMPC_POLISH_ROUNDS_WARM : HMPC_POLISH_ROUNDS;
             if (mode != 3) {
                 double pinf = 0, pmove = 0;
                 ROWS_BEGIN(k, rw)
@@ -2052,7 +2126,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // multipliers (what is left to settle are the components that matter, of the size of the
                             // second level's rounding; the slow ones are in place)
                             act = (level == 1 && round + 1 < max_rounds) ? 2 : 0;
-                        } else if (warm_try && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
+                        } else if (WARM && warm_try && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
                             // the handed-down set is not near this node's optimum (the node is infeasible, or fixing the
                             // binary moved the solution): dropped after this one factorisation
                         } else if (round + 1 < max_rounds) {
@@ -2109,7 +2183,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 tau = 1.0;
                 status = HMPC_OPTIMAL;
                 polished_out = true;
-                handed_out = warm_try;
+                handed_out = WARM && warm_try;
                 __syncthreads();
                 break;
             }
@@ -2118,7 +2192,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             ROWS_BEGIN(k, rw)
                 if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = R.prod(k, rw.e);
             ROWS_END
-            if (warm_try) { // the hand-down did not verify: back to the cold start (multipliers and slacks are at 1 again)
+            if (WARM && warm_try) { // the hand-down did not verify: back to the cold start (multipliers and slacks are at 1 again)
                 warm_try = false;
                 for (int o = lane; o < n; o += D::kNT) S.w[o] = 0.0;
                 __syncthreads();
@@ -2210,6 +2284,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 }
                 // residual of the three linear blocks at the combined direction (x_0 and fixed
                 // binaries are met by construction), then one correction solve
+                term_cols<D, RM>(p, S, lane, S.e);
                 for (int o = lane; o < n; o += D::kNT) {
                     const int t = o / nz < T ? o / nz : T;
                     const int j = o - t * nz, dim = t < T ? nz : nx;
@@ -2420,7 +2495,7 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
 
 // KF / KB / KT: register slots of the static row map ([F G] rows, bound rows, terminal-set rows) for the
 // compile-time shapes; all zero for the generic kernel (list row map, rows in the global slab).
-template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW>
+template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW, bool WARM = false>
 __global__ void __launch_bounds__(NW * WAVE) HMPC_KERNEL_ATTR
 hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace, const int32_t *__restrict__ order, const DevWarm warm)
@@ -2549,9 +2624,12 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         bool polished = false, weak = false, handed = false;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
-        const int wrow = warm.index ? warm.index[qp] : -1; // the parent's record, if one is handed down
-        const double *wprim = wrow >= 0 ? warm.primal + (size_t)wrow * p.n_primal : nullptr;
-        const double *wdual = wrow >= 0 ? warm.dual + (size_t)wrow * p.n_dual : nullptr;
+        const double *wprim = nullptr, *wdual = nullptr; // the parent's record, if one is handed down
+        if constexpr (WARM) {
+            const int wrow = warm.index ? warm.index[qp] : -1;
+            wprim = wrow >= 0 ? warm.primal + (size_t)wrow * p.n_primal : nullptr;
+            wdual = wrow >= 0 ? warm.dual + (size_t)wrow * p.n_dual : nullptr;
+        }
         // Lazy terminal set: an infeasibility proof without the terminal-set rows is a proof for the
         // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
         // is the node's optimum.  Otherwise solve again with every row.
@@ -2559,7 +2637,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual);
+            status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual);
             if (term_on == 0) it1 = its; else it2 = its;
             if (term_on == 0) {
                 bool done = status == HMPC_INFEASIBLE;
@@ -2648,6 +2726,7 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
 typedef void (*hmpc_kernel_t)(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *, const int32_t *, const DevWarm);
 struct hmpc_kernel_choice {
     hmpc_kernel_t fn;
+    hmpc_kernel_t fn_warm; // the same kernel with the parent -> child hand-down compiled in (launches with hmpc_warm)
     int waves;
     int kc;  // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
     int big; // generic kernel with lists and factor in global memory (Dims::kBig)
@@ -2681,7 +2760,7 @@ static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &k
 }
 #define HMPC_TRY(NX, NU, NUB, F, Bn, Tn, NWv) \
     if (kf <= F && kb <= Bn && kt <= Tn && p.kcol <= Dims<NX, NU, NUB, NWv>::kKC)       \
-        return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, NWv, Dims<NX, NU, NUB, NWv>::kKC, 0};
+        return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv, true>, NWv, Dims<NX, NU, NUB, NWv>::kKC, 0};
 static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
 {
     const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr || getenv("HMPC_FORCE_BIG") != nullptr;
@@ -2704,13 +2783,13 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
     }
     // generic kernel; its streaming form when lists and factor do not fit one CU's LDS
     if (hmpc_lds_bytes(p, 0, 0) > 160 * 1024 || getenv("HMPC_FORCE_BIG")) {
-        if (nw == 1) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 1>, 1, 0, 1};
-        if (nw == 2) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 2>, 2, 0, 1};
-        return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>, 4, 0, 1};
+        if (nw == 1) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 1>, hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 1, true>, 1, 0, 1};
+        if (nw == 2) return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 2>, hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 2, true>, 2, 0, 1};
+        return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>, hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4, true>, 4, 0, 1};
     }
-    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, 1, 0, 0};
-    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, 2, 0, 0};
-    return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, 4, 0, 0};
+    if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1, true>, 1, 0, 0};
+    if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2, true>, 2, 0, 0};
+    return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4, true>, 4, 0, 0};
 }
 #undef HMPC_TRY
 #endif
