@@ -40,6 +40,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 
 
+def progress(msg):
+    """One line on stderr per stage: a run that is silent for minutes is taken to be hung by the GPU pool."""
+    sys.stderr.write('[bench %7.1f s] %s\n' % (time.perf_counter() - T_START, msg))
+    sys.stderr.flush()
+
+
+T_START = time.perf_counter()
+
+
 def cpu_baseline(ctrl, x0, fix):
     """The CPU oracle (a float64 port of the same QP statement, oracle/hsde_qp.c) timed on the
     host cores of this box, on the same frontier.  A reported baseline, not the thing shipped."""
@@ -219,20 +228,13 @@ def other_configs(dev):
     for t in range(T):
         rr = c4.qp.solve_batch(x0, leaf)
         leaf[0, t * nub:(t + 1) * nub] = (rr['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
-    rng = np.random.default_rng(0)
-    f = np.full((256, T * nub), -1, np.int8)
-    for k in range(1, 256):
-        d = int(rng.integers(1, T * nub + 1))
-        f[k, :d] = leaf[0, :d]
-        if k % 2 == 0:
-            j = int(rng.integers(0, d))
-            f[k, j] = 1 - f[k, j]
-    f = np.tile(f, (4, 1))
+    f = dive_frontier(leaf[0], 4096, 0)
     r, _ = _device_rate(c4.qp, x0, f, dev, reps=3, warm=1)
     r['algorithmic_bytes_per_qp'] = c4.layout.bytes_per_qp()
     r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
     r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: lists and Riccati factor in global memory)'
-    out['random_mld_nx20_nu14_N30_dive_frontier_1024'] = r
+    r['frontier'] = '4096 distinct nodes: prefixes of a dive to a feasible leaf, every other one with one binary flipped (random prefixes of this generator are all infeasible)'
+    out['random_mld_nx20_nu14_N30_dive_frontier_4096'] = r
     return out
 
 
@@ -324,6 +326,7 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
     from warm_start_hmpc_amd.fleet import FleetMPC
     for K, spec, hand in ((1, 4, True), (1, 4, False), (64, 2, True), (256, 0, True), (1024, 0, True), (1024, 0, False)):
         errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
+        progress('fleet of %d loops (hand-down %s)' % (K, hand))
         fl = FleetMPC(ctrl, K, handdown=hand)
         fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], frontier_width=8, speculation=spec)   # warm-up (allocations)
         cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], frontier_width=8, speculation=spec)
@@ -345,6 +348,7 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
     K = 1024
     errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
     for parts in (2, 4):
+        progress('%d parallel fleets' % parts)
         closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 2, errs[:, :2], parts=parts, frontier_width=8)           # warm-up
         cold = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 1, errs[:, :1], parts=parts, frontier_width=8)
         st = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), steps + 1, errs, parts=parts, frontier_width=8)
@@ -378,6 +382,25 @@ def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05, x_center=None):
         n += len(fix)
     fix, parent, x0 = np.concatenate(fixes)[:B], np.concatenate(parents)[:B].astype(np.int32), np.concatenate(xs)[:B]
     return np.ascontiguousarray(x0), np.ascontiguousarray(fix), parent
+
+
+def dive_frontier(leaf, count, seed):
+    """BASELINE configs[4] frontier: `count` DISTINCT nodes -- prefixes (random depth) of a dive to a feasible leaf, every
+    other one with one of its fixed binaries flipped (random prefixes of the random MLD are all infeasible)."""
+    rng = np.random.default_rng(seed)
+    n = leaf.size
+    seen, rows = {bytes(np.full(n, -1, np.int8))}, [np.full(n, -1, np.int8)]
+    while len(rows) < count:
+        d = int(rng.integers(1, n + 1))
+        row = np.full(n, -1, np.int8)
+        row[:d] = leaf[:d]
+        if len(rows) % 2 == 0:
+            j = int(rng.integers(0, d))
+            row[j] = 1 - row[j]
+        if row.tobytes() not in seen:
+            seen.add(row.tobytes())
+            rows.append(row)
+    return np.array(rows)
 
 
 def shard(total, world, rank):
@@ -451,15 +474,7 @@ def main():
         for t in range(T):
             rr = ctrl.qp.solve_batch(x0_h, leaf)
             leaf[0, t * nub:(t + 1) * nub] = (rr['primal'][0][:(T + 1) * 20].reshape(T + 1, 20)[t] @ Cj.T >= 0)
-        rng = np.random.default_rng(rank)
-        base = np.full((256, T * nub), -1, np.int8)
-        for k in range(1, 256):
-            d = int(rng.integers(1, T * nub + 1))
-            base[k, :d] = leaf[0, :d]
-            if k % 2 == 0:
-                j = int(rng.integers(0, d))
-                base[k, j] = 1 - base[k, j]
-        fix_h = np.tile(base, (B // 256 + 1, 1))[:B]
+        fix_h = dive_frontier(leaf[0], B, rank)
     else:
         ctrl = make_controller('cart_pole_with_walls', T=40 if args.workload == 'cart_pole_n40' else None, backend='hip', device=local)
         T, nub = ctrl.T, ctrl.mld.nub
@@ -507,6 +522,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress('rank %d: frontier of %d nodes built' % (rank, B))
     for _ in range(args.warmup):
         step()
     barrier()
@@ -585,8 +601,10 @@ def main():
                 line['warm_start_shift'] = shift_bandwidth(ctrl, dev)
             except Exception as e:
                 line['warm_start_shift'] = {'error': str(e)}
+        progress('timed region done: %.3f ms per step' % (1e3 * elapsed / args.steps))
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
+            progress('cpu baseline done')
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.workload == 'cart_pole_n20':
             for key, fn in (('frontiers', lambda: secondary_frontiers(ctrl, dev, load_fixture('cart_pole_with_walls')['x_max'])), ('other_configs', lambda: other_configs(dev)),
                             ('mpc_steps_per_sec', lambda: mpc_steps_per_sec(ctrl)), ('offline_lps', offline_lps)):
@@ -594,6 +612,7 @@ def main():
                     line[key] = fn()
                 except Exception as e:  # secondary figures never hide the main line
                     line[key] = {'error': repr(e)}
+                progress('%s done' % key)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

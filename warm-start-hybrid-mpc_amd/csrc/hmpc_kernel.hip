@@ -980,6 +980,9 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
             // registers for the moment, loads independent), every entry is one sum over the wave -- as a loop over the
             // ~100 rows per entry (three dependent loads a term) this block took longer than the rest of the factorisation
             const ldsd *Dt = S.e + p.Toff;
+            if (p.nT == 0) { // (a problem without terminal set runs its only solve with term_on set: an empty block)
+                for (int q = lane; q < NZ * NZ; q += WAVE) TG[q] = 0.0;
+            }
             for (int r0 = 0; r0 < p.nT; r0 += WAVE) { // (two trips for the cart-pole's 102 facets)
                 const int row = r0 + lane;
                 const bool ok = row < p.nT;
