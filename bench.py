@@ -47,6 +47,9 @@ def progress(msg):
 
 
 T_START = time.perf_counter()
+if os.environ.get('BENCH_WATCHDOG'):     # diagnostic: where is the interpreter every N seconds
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ['BENCH_WATCHDOG']), repeat=True, file=sys.stderr)
 
 
 def cpu_baseline(ctrl, x0, fix):
@@ -394,7 +397,7 @@ def dive_frontier(leaf, count, seed):
         d = int(rng.integers(1, n + 1))
         row = np.full(n, -1, np.int8)
         row[:d] = leaf[:d]
-        if len(rows) % 2 == 0:
+        if rng.random() < 0.5 or len(seen) > n // 2:   # (there are only n distinct prefixes without a flip)
             j = int(rng.integers(0, d))
             row[j] = 1 - row[j]
         if row.tobytes() not in seen:
