@@ -442,7 +442,7 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 /* zwarm (optional, M entries, solver units, tau = 1): multipliers handed down by the parent node -- the active set is
  * read from them (z > 0: the parent's record is a polished vertex, exactly complementary) instead of from the iterate,
  * and k->w holds the parent's primal point with the child's prescribed components written over it. */
-static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm, int own)
+static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm)
 {
     int nz = p->nz, T = p->T;
     double rho = POLISH_RHO;
@@ -476,9 +476,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
     (void)zinf;
     /* (a hand-down that does not verify on the parent's set or after one exchange of rows is dropped: the child's
      * optimum is elsewhere -- typically the child is infeasible -- and every further round costs an iteration's worth) */
-    /* own: the set comes from this node's own first solve (terminal-set rows masked), now tried with those rows: they
-     * are expected to be violated -- the rounds below make the violated ones active -- so neither limit applies */
-    const int max_rounds = (zwarm && !own) ? POLISH_ROUNDS_WARM : POLISH_ROUNDS;
+    const int max_rounds = zwarm ? POLISH_ROUNDS_WARM : POLISH_ROUNDS;
     for (int round = 0; round < max_rounds; round++) {
         if (factor(p, k, fix) != 0) { return 0; }
         memcpy(cw, cw0, sizeof(double) * p->M); /* the proximal centre starts at the interior-point iterate */
@@ -541,7 +539,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
         if (getenv("ORACLE_QP_TRACE")) fprintf(stderr, "      polish round %d vmax %.3e zmin %.3e\n", round, vmax, zmin);
         /* a handed-down set whose point misses an inactive row by this much is not near the child's optimum (the child is
          * infeasible, or fixing the binary moved the solution): drop it after this one factorisation */
-        if (zwarm && !own && vmax > POLISH_WARM_VMAX * (1 + winf)) return 0;
+        if (zwarm && vmax > POLISH_WARM_VMAX * (1 + winf)) return 0;
         if (vmax <= es && zmin >= -ez) {
             if (level == 1 && round + 1 < max_rounds) {
                 /* verified at the second level: the same active set once more at the first, from these multipliers --
@@ -569,14 +567,11 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
 
 /* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
 static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, int do_polish, double ptol, double tol, double tol_inf, int max_iter,
-                     const double *wprimal, const double *wdual, int own_first,
+                     const double *wprimal, const double *wdual,
                      double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol, int *polished_out)
 {
     int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
     int mact = 0;
-    int status = ST_MAXITER, it = 0, extra_done = 0, polished = 0, npol = 0, weak = 0;
-    double last_alpha = 0, last_dtau = 0, last_dkap = 0;
-    double tau = 1.0, kap = 1.0;
     for (int t = 0; t < T; t++) {
         int m = mt(p, t), mg = m - 2 * nub, ro = p->roff[t];
         for (int r = 0; r < m; r++) {
@@ -584,28 +579,18 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             if (r >= mg) on = fix[t * nub + ((r - mg) % nub)] < 0;
             else if (!term_on && t == T - 1 && r >= p->nc) on = 0;   /* terminal-set rows masked */
             k->act[ro + r] = (unsigned char)on; mact += on;
+            k->s[ro + r] = 1.0; k->z[ro + r] = on ? 1.0 : 0.0;
         }
     }
-    /* ---- Second solve of a node (lazy terminal set) from its own first solve.  own_first: the workspace still holds the
-     * polished vertex of the first solve (k->w at tau = 1, k->z exactly complementary, zero on the masked terminal rows),
-     * and some terminal row is violated there.  The polish is run on that active set WITH the terminal rows: the violated
-     * ones change sides in its rounds.  If it verifies, the node costs a few factorisations instead of a second
-     * interior-point solve (~13-17 iterations: the nodes that set the makespan of a launch on closed-loop states);
-     * otherwise the cold start below runs as before. */
-    if (own_first && do_polish) {
-        double *zw = k->z2, winf0 = 0, zinf0 = 0;
-        for (int q = 0; q < M; q++) { zw[q] = k->act[q] ? k->z[q] : 0.0; if (zw[q] > zinf0) zinf0 = zw[q]; }
-        for (int i = 0; i < n; i++) if (fabs(k->w[i]) > winf0) winf0 = fabs(k->w[i]);
-        for (int i = 0; i < (T + 1) * nx; i++) if (fabs(k->lam[i]) > zinf0) zinf0 = fabs(k->lam[i]);
-        if (polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw, 1)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 3; it = 0; tau = 1.0; goto output; }
-    }
-    for (int q = 0; q < M; q++) { k->s[q] = 1.0; k->z[q] = k->act[q] ? 1.0 : 0.0; }
     memset(k->w, 0, sizeof(double) * n); memset(k->lam, 0, sizeof(double) * (T + 1) * nx);
     memset(k->nuf, 0, sizeof(double) * T * nub);
+    double tau = 1.0, kap = 1.0;
     /* prescribed components follow tau exactly */
     for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
     for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
 
+    int status = ST_MAXITER, it = 0, extra_done = 0, polished = 0, npol = 0, weak = 0;
+    double last_alpha = 0, last_dtau = 0, last_dkap = 0;
     /* ---- Parent -> child hand-down (the reference hands the parent's simplex basis to the child, controller.py:260-264,
      * subproblem_solution.py:37-43).  wprimal / wdual: the PARENT's record (output conventions).  Its active set -- the rows
      * with a positive multiplier, minus the bound rows of binaries the child fixes -- is tried by the polish before the
@@ -635,7 +620,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             }
         }
         for (int i = 0; i < (T + 1) * nx; i++) if (fabs(wdual[i]) * p->cs > zinf0) zinf0 = fabs(wdual[i]) * p->cs;
-        if (winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw, 0)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
+        if (winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
         memset(k->w, 0, sizeof(double) * n);
         for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
         for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
@@ -715,7 +700,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             const int ready = do_polish && (npol < POLISH_ATTEMPTS ? (acceptable || exhausted || (status != ST_OPTIMAL && rcinf / tau <= ptol * (1 + winf + x0inf) &&
                                                                         rdinf / tau <= ptol * (1 + zinf) && gap <= gptol))
                                                                    : (npol == POLISH_ATTEMPTS && final_exit));
-            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha, NULL, 0)) { status = ST_OPTIMAL; polished = npol; break; } }
+            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha, NULL)) { status = ST_OPTIMAL; polished = npol; break; } }
             if (acceptable) {
                 status = ST_OPTIMAL;
                 if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tol * (1 + zinf)) || extra_done >= 3 || it == max_iter) break;
@@ -939,7 +924,6 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
 {
     if (nx + nu > 64 || nx > 32) return -1;
     prob_t *p = prob_create(nx, nu, nub, T, nc, ncL, nq, nr, nqT, A, B, F, G, h, FL, GL, hL, Q, R, QT);
-    const int own_second = getenv("ORACLE_QP_COLD_SECOND") == NULL; /* (diagnostic switch: second solves from the cold start) */
     int np_ = (T + 1) * nx + T * nu;
     int nd = (T + 1) * nx + (T - 1) * nc + ncL + 2 * T * nub + T * nq + nqT + T * nr;
 #ifdef _OPENMP
@@ -962,10 +946,10 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
             const int wi = (warm_index && warm_primal && warm_dual) ? warm_index[b] : -1;
             const double *wp = wi >= 0 ? warm_primal + (size_t)wi * np_ : NULL, *wd = wi >= 0 ? warm_dual + (size_t)wi * nd : NULL;
             if (ncL > nc && lazy_terminal) {
-                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 0, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
                 if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)) && (second = 1))
-                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, own_second && st == ST_OPTIMAL && (pol & 0xff) > 0, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
-            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 0, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
+            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
             status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol | (second ? 0x200 : 0);
         }
         work_free(k);

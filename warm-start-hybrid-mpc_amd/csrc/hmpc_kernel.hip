@@ -46,7 +46,6 @@
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
-#define HMPC_RETRY (-1) // internal: the second solve from the node's own first did not verify, solve it from the cold start
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
 #define HMPC_POLISH_WARM_VMAX 1e-2 // a handed-down set whose point misses an inactive row by more is dropped at once
 #ifndef HMPC_KERNEL_ATTR
@@ -1723,63 +1722,29 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 // launch, measured) -- a launch without hand-down runs the kernel it always ran.
 template <class D, int RS, class RM, bool WARM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual,
-                  bool own_first)
+                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
     int mact = 0;
     rm.prepare(p, S, lane, term_on);
-    double tau = 1.0, kap = 1.0, x0inf = 0;
-    // SECOND SOLVE OF A NODE FROM ITS OWN FIRST (lazy terminal set).  own_first: the first solve, with the terminal-set
-    // rows masked, ended in a polished vertex that violates some of them; iterate (S.w at tau = 1) and multipliers (R.z,
-    // exactly complementary, zero on the rows that were masked) are still in place.  The polish passes of the loop below are
-    // run on that active set WITH the terminal rows -- the violated ones change sides in its rounds.  If the result verifies
-    // the node costs a few factorisations instead of a second interior-point solve (13-17 iterations: on closed-loop
-    // states these nodes set the makespan of a launch); otherwise HMPC_RETRY is returned and the caller asks for the cold
-    // second solve.  Same steps as oracle/hsde_qp.c.
-    bool own_try = false;
-    double own_w = 0, own_z = 0;
-    if (own_first && p.polish) {
-        for (int o = lane; o < n; o += D::kNT) own_w = fmax(own_w, fabs(S.w[o]));
-        for (int o = lane; o < (T + 1) * nx; o += D::kNT) own_z = fmax(own_z, fabs(S.lam[o]));
-        ROWS_BEGIN(k, rw)
-            double d = 0.0;
-            if (rm.active(p, S, k, rw)) {
-                const double zr = R.z(k, rw.e);
-                own_z = fmax(own_z, zr);
-                R.prod(k, rw.e) = 1.0;
-                if (zr > 0.0) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr; }
-                else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w); }
-                R.D(k, rw.e) = d;
-            }
-            S.e[rw.e] = d;
-        ROWS_END
-        {
-            double v[2] = {own_w, own_z};
-            const int op[2] = {1, 1};
-            block_reduce<D, 2>(v, op, S.red, lane);
-            own_w = v[0]; own_z = v[1];
-        }
-        own_try = true;
-        __syncthreads();
-    } else {
-        ROWS_BEGIN(k, rw)
-            const bool on = rm.active(p, S, k, rw);
-            mact += on;
-            R.s(k, rw.e) = 1.0;
-            R.z(k, rw.e) = on ? 1.0 : 0.0;
-        ROWS_END
-        mact = (int)block_sum<D>((double)mact, S.red, lane);
-        for (int i = lane; i < n; i += D::kNT) S.w[i] = 0.0;
-        for (int i = lane; i < (T + 1) * nx; i += D::kNT) S.lam[i] = 0.0;
-        for (int i = lane; i < T * nub; i += D::kNT) S.nuf[i] = 0.0;
-        __syncthreads();
-        set_prescribed<D>(p, S, lane, tau);
-        __syncthreads();
-        for (int i = lane; i < nx; i += D::kNT) x0inf = fmax(x0inf, fabs(S.x0[i]));
-        x0inf = block_max<D>(x0inf, S.red, lane);
-    }
+    ROWS_BEGIN(k, rw)
+        const bool on = rm.active(p, S, k, rw);
+        mact += on;
+        R.s(k, rw.e) = 1.0;
+        R.z(k, rw.e) = on ? 1.0 : 0.0;
+    ROWS_END
+    mact = (int)block_sum<D>((double)mact, S.red, lane);
+    for (int i = lane; i < n; i += D::kNT) S.w[i] = 0.0;
+    for (int i = lane; i < (T + 1) * nx; i += D::kNT) S.lam[i] = 0.0;
+    for (int i = lane; i < T * nub; i += D::kNT) S.nuf[i] = 0.0;
+    double tau = 1.0, kap = 1.0;
+    __syncthreads();
+    set_prescribed<D>(p, S, lane, tau);
+    __syncthreads();
+    double x0inf = 0;
+    for (int i = lane; i < nx; i += D::kNT) x0inf = fmax(x0inf, fabs(S.x0[i]));
+    x0inf = block_max<D>(x0inf, S.red, lane);
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
     polished_out = false;
@@ -1795,10 +1760,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // One loop runs the interior-point iterations (mode 0) and the passes of the ACTIVE-SET POLISH (mode 1: a new
     // active set, with factorisation; mode 2: a further multiplier step with the factorisation at hand): the
     // polish reuses the factorisation and the constant-direction solve below instead of owning copies of them.
-    int mode = own_try ? 1 : 0, round = 0, al = 0;
+    int mode = 0, round = 0, al = 0;
     int level = 0; // penalty of the polish in progress: 0 first level; 1 second; 2 back at the first for the last digits
 #define HMPC_RHO_OF(level) ((level) == 1 ? HMPC_POLISH_RHO2 : HMPC_POLISH_RHO)
-    double rg = 0, mu = 0, wPw = 0, winf = own_w, zinf = own_z;
+    double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
     // PARENT -> CHILD HAND-DOWN (the reference hands the parent's simplex basis to the child: controller.py:260-264,
     // subproblem_solution.py:37-43).  wprim / wdual: the parent's record.  Its active set -- the rows with a positive
     // multiplier that still exist in this node -- is tried by the polish passes below BEFORE the first interior-point
@@ -1807,7 +1772,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // not verify within HMPC_POLISH_ROUNDS_WARM rounds, or misses a row by HMPC_POLISH_WARM_VMAX, is dropped and the cold
     // start below runs untouched.  Same steps as oracle/hsde_qp.c.
     bool warm_try = false;
-    if constexpr (WARM) if (wprim != nullptr && p.polish && !own_try) {
+    if constexpr (WARM) if (wprim != nullptr && p.polish) {
         const int nu = D::nu(p);
         for (int o = lane; o < n; o += D::kNT) {
             const int t = o / nz < T ? o / nz : T;
@@ -2227,10 +2192,6 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             }
             // not verified: the iterate is intact but for the slots that held the classes; its residuals are
             // recomputed (S.rd served as scratch) and the interior-point iteration goes on
-            if (own_try) { // the node's own active set did not carry over: the caller asks for the cold second solve
-                status = HMPC_RETRY;
-                break;
-            }
             ROWS_BEGIN(k, rw)
                 if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = R.prod(k, rw.e);
             ROWS_END
@@ -2663,7 +2624,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         }
 #endif
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
-        bool polished = false, weak = false, handed = false;
+        bool polished = false, weak = false, handed = false, second = false;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
         const double *wprim = nullptr, *wdual = nullptr; // the parent's record, if one is handed down
@@ -2676,21 +2637,17 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
         // is the node's optimum.  Otherwise solve again with every row.
         const int first = (p.nT > 0 && p.lazy) ? 0 : 1;
-        bool second = false, own = false;
-        for (int term_on = first;;) { // (one call site: the solve is a large inlined body)
+        for (int term_on = first; term_on < 2; term_on++) {
             int its = 0;
             S.term_on = term_on;
-            status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, own);
-            if (status == HMPC_RETRY) { own = false; continue; } // the node's own active set did not carry over: cold second solve
-            if (term_on == 0) it1 = its; else it2 += its;
-            if (term_on == 1) break;
-            bool done = status == HMPC_INFEASIBLE;
-            if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
-            if (done) break;
-            // the terminal-set rows are needed: from the polished vertex of the first solve if there is one
-            own = status == HMPC_OPTIMAL && polished;
-            second = true;
-            term_on = 1;
+            status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual);
+            if (term_on == 0) it1 = its; else it2 = its;
+            if (term_on == 0) {
+                bool done = status == HMPC_INFEASIBLE;
+                if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
+                if (done) break;
+                second = true; // the terminal-set rows are needed: the node is solved again with every row
+            }
         }
         __syncthreads();
         {
