@@ -221,6 +221,9 @@ int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
  * round than its parent receives the parent's record, which already lies in the fleet's HBM pools.  enable: 1 / 0, < 0:
  * leave as is.  verified (nullable): solves since creation whose handed-down active set verified. */
 int hmpc_fleet_handdown(hmpc_fleet *f, int32_t enable, int64_t *verified);
+/* Host wall time of the fleet's calls by phase since creation (5 doubles, seconds): candidate selection, staging of the
+ * rounds' nodes, device (copies, kernel, synchronisation), consumption of the results, node shifts. */
+int hmpc_fleet_timing(const hmpc_fleet *f, double *seconds5);
 
 /* ---- Incumbent exchange between the GPUs of a node (RCCL over xGMI) ----------------------------------
  * A frontier is sharded by node (node k to rank k mod nranks; nodes are independent, no data-path collective).

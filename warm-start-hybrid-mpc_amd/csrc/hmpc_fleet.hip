@@ -17,6 +17,7 @@
 // Semantics per tree are those of warm_start_hmpc_amd/batched.py (feedforward_many / construct_warm_start_many),
 // against which tests/test_fleet.py checks it step by step.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -69,6 +70,7 @@ struct hmpc_fleet {
     double *d_kx0 = nullptr, *d_ku0 = nullptr, *d_ke0 = nullptr, *h_k = nullptr; // K x nx, K x nu, K x nx (pinned: 3 blocks)
     double *h_prow = nullptr;                                                  // pinned: one primal row
     long long rounds = 0, launched = 0, handed = 0;
+    double t_select = 0, t_stage = 0, t_device = 0, t_consume = 0, t_shift = 0; // host wall time by phase (hmpc_fleet_timing)
     bool broken = false; // a call failed midway: the trees are half updated until hmpc_fleet_reset(f, -1)
 };
 
@@ -263,8 +265,10 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
     std::vector<Launch> launch;
     std::vector<int8_t> level, next; // identifiers of one level of a speculative expansion
     auto key_of = [&](const int8_t *fx, int depth) { return std::string((const char *)fx, (size_t)depth); };
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
         // candidates of every tree: alive, bound below the incumbent; the `width` smallest bounds, first wins ties
+        double t0 = now();
         size_t npick = 0;
         for (int k = 0; k < K; k++) {
             FleetTree &t = f->trees[k];
@@ -278,7 +282,9 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             picks[k] = order;
             npick += order.size();
         }
+        f->t_select += now() - t0;
         if (npick == 0) break;
+        t0 = now();
         // what has to be launched: picked nodes without a cached result, and their speculative descendants
         launch.clear();
         size_t B = 0;
@@ -329,6 +335,8 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             }
             B = b;
         }
+        f->t_stage += now() - t0;
+        t0 = now();
         if (B > 0) {
             HIPCHK(hipMemcpyAsync(f->d_fix, f->h_fix, B * nfix, hipMemcpyHostToDevice, f->stream));
             HIPCHK(hipMemcpyAsync(f->d_x0, f->h_x0, B * nx * sizeof(double), hipMemcpyHostToDevice, f->stream));
@@ -344,6 +352,8 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             HIPCHK(hipMemcpy2DAsync(f->h_nu, 2 * nfix * sizeof(double), rows + o_lb, p.n_dual * sizeof(double), 2 * nfix * sizeof(double), B,
                                     hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipStreamSynchronize(f->stream));
+            f->t_device += now() - t0;
+            t0 = now();
             f->rounds++;
             f->launched += (long long)B;
             for (size_t q = 0; q < B; q++) {
@@ -363,6 +373,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             f->used += B;
         }
         // prune / incumbent / branch, node by node in selection order (branch_and_bound.py:476-489)
+        struct Tick { double &acc; double t0; ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; } } tick{f->t_consume, t0};
         for (int k = 0; k < K; k++) {
             FleetTree &t = f->trees[k];
             for (int i : picks[k]) {
@@ -430,6 +441,8 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
     if (!f || !e0) return fail(HMPC_EINVAL, "fleet: null argument");
     if (f->broken) return fail(HMPC_EINVAL, "fleet: an earlier call failed midway; reset the fleet (hmpc_fleet_reset(f, -1)) first");
     struct Guard { hmpc_fleet *f; bool ok = false; ~Guard() { if (!ok) f->broken = true; } } guard{f};
+    struct Tick { double &acc; double t0; ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; } }
+        tick{f->t_shift, std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()};
     hmpc_handle *h = f->h;
     HIPCHK(hipSetDevice(h->device));
     const DevProb &p = h->dp;
@@ -531,6 +544,15 @@ extern "C" int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *l
     if (!f) return fail(HMPC_EINVAL, "fleet: null");
     if (rounds) *rounds = f->rounds;
     if (launched) *launched = f->launched;
+    return HMPC_OK;
+}
+
+// Host wall time of the fleet's calls by phase since creation, seconds: candidate selection, staging of a round's nodes,
+// device (copies, kernel, synchronisation), consumption of the results (prune / incumbent / branch), node shifts.
+extern "C" int hmpc_fleet_timing(const hmpc_fleet *f, double *seconds5)
+{
+    if (!f || !seconds5) return fail(HMPC_EINVAL, "fleet: null");
+    seconds5[0] = f->t_select; seconds5[1] = f->t_stage; seconds5[2] = f->t_device; seconds5[3] = f->t_consume; seconds5[4] = f->t_shift;
     return HMPC_OK;
 }
 

@@ -66,7 +66,10 @@ class FleetMPC(object):
         r, n, v = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         self.qp._check(self.qp.lib.hmpc_fleet_stats(self._f, ctypes.byref(r), ctypes.byref(n)))
         self.qp._check(self.qp.lib.hmpc_fleet_handdown(self._f, -1, ctypes.byref(v)))
-        return dict(rounds=r.value, launched=n.value, handed=v.value)
+        t = (ctypes.c_double * 5)()
+        self.qp._check(self.qp.lib.hmpc_fleet_timing(self._f, t))
+        return dict(rounds=r.value, launched=n.value, handed=v.value,
+                    seconds=dict(zip(('select', 'stage', 'device', 'consume', 'shift'), [float(x) for x in t])))
 
     def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0):
         """K closed loops from the same x0 under prescribed model errors (K, n_steps, nx) -- the shape of

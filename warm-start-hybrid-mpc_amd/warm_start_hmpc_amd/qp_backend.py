@@ -99,6 +99,8 @@ def load_library():
         lib.hmpc_fleet_shift.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.hmpc_fleet_stats.restype = ctypes.c_int
         lib.hmpc_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.hmpc_fleet_timing.restype = ctypes.c_int
+        lib.hmpc_fleet_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double)]
         lib.hmpc_fleet_handdown.restype = ctypes.c_int
         lib.hmpc_fleet_handdown.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64)]
         lib.hmpc_comm_unique_id.restype = ctypes.c_int
@@ -124,7 +126,7 @@ EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_la
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
+                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
 
 
