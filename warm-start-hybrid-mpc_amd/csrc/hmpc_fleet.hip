@@ -42,6 +42,7 @@ struct FleetTree {
     int n = 0;
     double ub = std::numeric_limits<double>::infinity();
     int inc = -1;               // incumbent node
+    int32_t inc_row = -1;       // its row in the primal pool
     std::vector<double> primal; // its primal row
     int solves = 0;
     bool running = true;        // false once the MIQP of a step was infeasible (the loop has ended)
@@ -68,11 +69,21 @@ struct hmpc_fleet {
     double *d_lb = nullptr, *h_lb = nullptr, *d_lb_out = nullptr;
     uint8_t *d_flags = nullptr, *h_flags = nullptr;
     double *d_kx0 = nullptr, *d_ku0 = nullptr, *d_ke0 = nullptr, *h_k = nullptr; // K x nx, K x nu, K x nx (pinned: 3 blocks)
-    double *h_prow = nullptr;                                                  // pinned: one primal row
+    double *h_prow = nullptr, *d_prow = nullptr;                               // K primal rows: pinned / device (incumbents of a step)
+    int32_t *h_inc = nullptr, *d_inc = nullptr;                                // K: pool row of each loop's incumbent
     long long rounds = 0, launched = 0, handed = 0;
     double t_select = 0, t_stage = 0, t_device = 0, t_consume = 0, t_shift = 0; // host wall time by phase (hmpc_fleet_timing)
     bool broken = false; // a call failed midway: the trees are half updated until hmpc_fleet_reset(f, -1)
 };
+
+// Rows `rows[k]` of a pool into a dense block (the incumbents' primal rows at the end of a step: one launch and one copy
+// instead of one synchronous copy per new incumbent -- 1024 loops x ~17 us were a quarter of a step's wall time).
+__global__ void hmpc_gather_rows(const double *__restrict__ pool, const int32_t *__restrict__ rows, int width, double *__restrict__ out)
+{
+    const int k = blockIdx.x, r = rows[k];
+    if (r < 0) return;
+    for (int j = threadIdx.x; j < width; j += blockDim.x) out[(size_t)k * width + j] = pool[(size_t)r * width + j];
+}
 
 namespace {
 
@@ -198,7 +209,8 @@ extern "C" int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out)
     }
     if (hipStreamCreateWithFlags(&f->stream, hipStreamNonBlocking) != hipSuccess) { delete f; return fail(HMPC_EDEVICE, "fleet: cannot create a stream"); }
     int bad = dev_alloc(&f->d_kx0, (size_t)K * p.nx) | dev_alloc(&f->d_ku0, (size_t)K * p.nu) | dev_alloc(&f->d_ke0, (size_t)K * p.nx);
-    bad |= pin_alloc(&f->h_k, (size_t)K * (2 * p.nx + p.nu)) | pin_alloc(&f->h_prow, (size_t)p.n_primal);
+    bad |= pin_alloc(&f->h_k, (size_t)K * (2 * p.nx + p.nu)) | pin_alloc(&f->h_prow, (size_t)K * p.n_primal) | dev_alloc(&f->d_prow, (size_t)K * p.n_primal);
+    bad |= pin_alloc(&f->h_inc, (size_t)K) | dev_alloc(&f->d_inc, (size_t)K);
     if (bad) { hmpc_fleet_destroy(f); return fail(HMPC_EDEVICE, "fleet: cannot allocate"); }
     *out = f;
     return HMPC_OK;
@@ -214,10 +226,11 @@ extern "C" int hmpc_fleet_destroy(hmpc_fleet *f)
         if (f->pool[s]) (void)hipFree(f->pool[s]);
         if (f->dobj[s]) (void)hipFree(f->dobj[s]);
     }
-    for (void *d : {(void *)f->d_kx0, (void *)f->d_ku0, (void *)f->d_ke0, (void *)f->ppool})
+    for (void *d : {(void *)f->d_kx0, (void *)f->d_ku0, (void *)f->d_ke0, (void *)f->ppool, (void *)f->d_prow, (void *)f->d_inc})
         if (d) (void)hipFree(d);
     if (f->h_k) (void)hipHostFree(f->h_k);
     if (f->h_prow) (void)hipHostFree(f->h_prow);
+    if (f->h_inc) (void)hipHostFree(f->h_inc);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
     return HMPC_OK;
@@ -255,7 +268,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
     const double inf = std::numeric_limits<double>::infinity();
     for (int k = 0; k < K; k++) {
         FleetTree &t = f->trees[k];
-        t.ub = inf; t.inc = -1; t.solves = 0;
+        t.ub = inf; t.inc = -1; t.inc_row = -1; t.solves = 0;
         t.cache.clear();
         std::memcpy(t.x0.data(), x0 + (size_t)k * nx, nx * sizeof(double));
     }
@@ -394,8 +407,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                 if (d == nfix) { // every binary fixed: new incumbent
                     t.ub = obj;
                     t.inc = i;
-                    HIPCHK(hipMemcpy(f->h_prow, f->ppool + (size_t)e.row * p.n_primal, p.n_primal * sizeof(double), hipMemcpyDeviceToHost));
-                    t.primal.assign(f->h_prow, f->h_prow + p.n_primal);
+                    t.inc_row = e.row; // (its primal row is fetched once, at the end of the step, with the others')
                 } else { // branch on the next binary in time; child bound = parent bound + multiplier of the tightened bound
                     for (int v = 0; v < 2; v++) {
                         const size_t c = t.n;
@@ -412,6 +424,22 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                     t.alive[i] = 0;
                 }
             }
+        }
+    }
+    {   // the incumbents' primal rows: one gather launch, one copy
+        bool any = false;
+        for (int k = 0; k < K; k++) {
+            f->h_inc[k] = (f->trees[k].running && f->trees[k].inc >= 0) ? f->trees[k].inc_row : -1;
+            any |= f->h_inc[k] >= 0;
+        }
+        if (any) {
+            HIPCHK(hipMemcpyAsync(f->d_inc, f->h_inc, (size_t)K * sizeof(int32_t), hipMemcpyHostToDevice, f->stream));
+            hipLaunchKernelGGL(hmpc_gather_rows, dim3(K), dim3(256), 0, f->stream, (const double *)f->ppool, (const int32_t *)f->d_inc, p.n_primal, f->d_prow);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(f->h_prow, f->d_prow, (size_t)K * p.n_primal * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+            HIPCHK(hipStreamSynchronize(f->stream));
+            for (int k = 0; k < K; k++)
+                if (f->h_inc[k] >= 0) f->trees[k].primal.assign(f->h_prow + (size_t)k * p.n_primal, f->h_prow + (size_t)(k + 1) * p.n_primal);
         }
     }
     for (int k = 0; k < K; k++) {
