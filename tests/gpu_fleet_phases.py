@@ -1,6 +1,7 @@
-"""Diagnostic (GPU box): where a fleet step spends its host wall time (hmpc_fleet_timing).
+"""Diagnostic (GPU box): where a fleet step spends its host wall time (hmpc_fleet_timing), cold step and warm steps apart.
     python tests/gpu_fleet_phases.py [loops] [steps]"""
 import sys
+from time import perf_counter
 
 import numpy as np
 from conftest import ROOT  # noqa: F401
@@ -13,17 +14,30 @@ x_max = load_fixture('cart_pole_with_walls')['x_max']
 ctrl = make_controller('cart_pole_with_walls', backend='hip')
 errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
 X0 = np.array([0., 0., 1., 0.])
+
+
+def show(tag, wall, a, b):
+    d = {k: b['seconds'][k] - a['seconds'][k] for k in b['seconds']}
+    print('   %-10s %.3f s wall; rounds %d, nodes %d (hand-down verified %d); host wall by phase: ' % (tag, wall, b['rounds'] - a['rounds'], b['launched'] - a['launched'], b['handed'] - a['handed'])
+          + ', '.join('%s %.3f' % kv for kv in d.items()) + ', python %.3f' % (wall - sum(d.values())))
+
+
 for hand in (True, False):
     fl = FleetMPC(ctrl, K, handdown=hand)
-    fl.closed_loop(X0, 2, errs[:, :2], frontier_width=8)
-    cold = fl.closed_loop(X0, 1, errs[:, :1], frontier_width=8)
-    s0 = fl.stats()
-    st = fl.closed_loop(X0, steps + 1, errs, frontier_width=8)
-    s1 = fl.stats()
-    # warm steps only: subtract one cold step measured just before
-    c0 = fl.stats()
-    d = {k: s1['seconds'][k] - s0['seconds'][k] for k in s1['seconds']}
-    wall = st['wall']
-    print('%d loops, hand-down %s: %d steps in %.3f s (incl. one cold step of %.3f s); rounds %d, nodes launched %d'
-          % (K, hand, steps + 1, wall, cold['wall'], s1['rounds'] - s0['rounds'], s1['launched'] - s0['launched']))
-    print('   host wall by phase: ' + ', '.join('%s %.3f s' % kv for kv in d.items()) + ', python %.3f s' % (wall - sum(d.values())))
+    fl.closed_loop(X0, 2, errs[:, :2], frontier_width=8)      # warm-up (allocations)
+    fl.reset()
+    xs = np.repeat(X0[None], K, axis=0)
+    print('%d loops, hand-down %s' % (K, hand))
+    s0, t0 = fl.stats(), perf_counter()
+    r = fl.solve(xs, 8)
+    fl.shift(errs[:, 0])
+    xs = r['x1'] + errs[:, 0]
+    s1, t1 = fl.stats(), perf_counter()
+    show('cold step', t1 - t0, s0, s1)
+    for t in range(1, steps + 1):
+        r = fl.solve(xs, 8)
+        fl.shift(errs[:, t])
+        xs = r['x1'] + errs[:, t]
+    s2, t2 = fl.stats(), perf_counter()
+    show('%d warm' % steps, t2 - t1, s1, s2)
+    print('   => %.0f warm steps/s' % (K * steps / (t2 - t1)))
