@@ -3,6 +3,9 @@
 
     python profiles/summarise.py stats  <rocprof dir> <out.csv>            # kernel_stats.csv of a --kernel-trace --stats run
     python profiles/summarise.py pmc    <out.json> <rocprof dir> [...]     # counter_collection.csv of --pmc runs
+    python profiles/summarise.py pmc    <out.json> --grid 65536 <rocprof dir> [...]   # only launches of that many threads
+(round 3: bench.py builds its frontier with real branch-and-bound searches -- hundreds of small launches of the 2- and
+4-wave kernels before the timed ones; --grid keeps the launches of the timed kernel: 1024 workgroups x 64 threads)
 
 For counters the mean per launch of `hmpc_qp_kernel` (and, under 'shift_kernel', of `hmpc_shift_kernel`) is stored; launches that belong to the
 warm-up are included (the kernel does the same work in each).  FETCH_SIZE / WRITE_SIZE are in
@@ -30,8 +33,11 @@ def stats(d, out):
     shutil.copyfile(find(d, '_kernel_stats.csv')[0], out)
 
 
+GRID = None
+
+
 def pmc(out, dirs):
-    res = _pmc(dirs, 'hmpc_qp_kernel')
+    res = _pmc(dirs, 'hmpc_qp_kernel', grid=GRID)
     shift = _pmc(dirs, 'hmpc_shift_kernel', required=False)
     if shift:
         res['shift_kernel'] = shift      # the warm-start shift (bench.py: 65536 leaves per launch)
@@ -40,13 +46,15 @@ def pmc(out, dirs):
     print(json.dumps(res, indent=1))
 
 
-def _pmc(dirs, kernel, required=True):
+def _pmc(dirs, kernel, required=True, grid=None):
     acc = {}
     for d in dirs:
         for f in find(d, '_counter_collection.csv'):
             with open(f) as fh:
                 for row in csv.DictReader(fh):
                     if kernel not in row['Kernel_Name']:
+                        continue
+                    if grid is not None and int(row['Grid_Size']) != grid:
                         continue
                     a = acc.setdefault(row['Counter_Name'], {'sum': 0.0, 'launches': 0, 'kernel': row['Kernel_Name'],
                                                              'vgpr': row['VGPR_Count'], 'agpr': row['Accum_VGPR_Count'],
@@ -74,4 +82,8 @@ if __name__ == '__main__':
     if sys.argv[1] == 'stats':
         stats(sys.argv[2], sys.argv[3])
     else:
-        pmc(sys.argv[2], sys.argv[3:])
+        rest = sys.argv[3:]
+        if rest and rest[0] == '--grid':
+            GRID = int(rest[1])
+            rest = rest[2:]
+        pmc(sys.argv[2], rest)
