@@ -567,7 +567,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
 
 /* One QP.  Outputs are in the ORIGINAL (unscaled) problem. */
 static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, int term_on, int refine, int do_polish, double ptol, double tol, double tol_inf, int max_iter,
-                     const double *wprimal, const double *wdual,
+                     const double *wprimal, const double *wdual, int attempt_only,
                      double *obj, double *dobj, int *iters, double *primal, double *dual, double *term_viol, int *polished_out)
 {
     int nx = p->nx, nu = p->nu, nz = p->nz, T = p->T, nuc = p->nuc, nub = p->nub, M = p->M, n = T * nz + nx;
@@ -621,6 +621,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         }
         for (int i = 0; i < (T + 1) * nx; i++) if (fabs(wdual[i]) * p->cs > zinf0) zinf0 = fabs(wdual[i]) * p->cs;
         if (winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
+        if (attempt_only) return -1; /* (the caller goes on with the regular sequence of solves) */
         memset(k->w, 0, sizeof(double) * n);
         for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
         for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b] * tau;
@@ -946,10 +947,27 @@ int oracle_solve_batch(int nx, int nu, int nub, int T, int nc, int ncL, int nq, 
             const int wi = (warm_index && warm_primal && warm_dual) ? warm_index[b] : -1;
             const double *wp = wi >= 0 ? warm_primal + (size_t)wi * np_ : NULL, *wd = wi >= 0 ? warm_dual + (size_t)wi * nd : NULL;
             if (ncL > nc && lazy_terminal) {
-                st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
-                if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)) && (second = 1))
-                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
-            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                /* A parent whose optimum lies on terminal-set rows hands those down too: its set is first tried WITH the
+                 * terminal rows (with them masked the point is far from the parent's and the hand-down drops out at
+                 * once, leaving a full first solve before the second one verifies).  Only an attempt: if it does not
+                 * verify, the regular sequence -- masked first, so that an infeasible node's ray carries no terminal
+                 * multipliers -- runs as without it. */
+                int parent_term = 0;
+                st = -1;
+                if (wd && do_polish) {
+                    const double *mu_last = wd + (T + 1) * nx + (size_t)(T - 1) * nc;
+                    for (int r = nc; r < ncL; r++) if (mu_last[r] > 0.0) parent_term = 1;
+                }
+                if (parent_term) {
+                    st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 1, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                    if (st >= 0) second = 1;
+                }
+                if (st < 0) {
+                    st = solve_one(p, k, xb, fb, 0, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 0, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
+                    if (!(st == ST_INFEASIBLE || (st == ST_OPTIMAL && tv < 0.0)) && (second = 1))
+                        st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 0, obj + b, dobj + b, &it2, pb, db, &tv, &pol);
+                }
+            } else st = solve_one(p, k, xb, fb, 1, refine, do_polish, ptol, tol, tol_inf, max_iter, wp, wd, 0, obj + b, dobj + b, &it1, pb, db, &tv, &pol);
             status[b] = st; iters[b] = it1 + it2; if (polished) polished[b] = pol | (second ? 0x200 : 0);
         }
         work_free(k);

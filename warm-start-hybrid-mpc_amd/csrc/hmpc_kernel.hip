@@ -46,6 +46,7 @@
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
+#define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
 #define HMPC_POLISH_WARM_VMAX 1e-2 // a handed-down set whose point misses an inactive row by more is dropped at once
 #ifndef HMPC_KERNEL_ATTR
@@ -1722,7 +1723,8 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
 // launch, measured) -- a launch without hand-down runs the kernel it always ran.
 template <class D, int RS, class RM, bool WARM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual)
+                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual,
+                  bool attempt_only)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -2196,6 +2198,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = R.prod(k, rw.e);
             ROWS_END
             if (WARM && warm_try) { // the hand-down did not verify: back to the cold start (multipliers and slacks are at 1 again)
+                if (attempt_only) { // (only an attempt: the caller runs the regular sequence of solves)
+                    status = HMPC_RETRY;
+                    break;
+                }
                 warm_try = false;
                 for (int o = lane; o < n; o += D::kNT) S.w[o] = 0.0;
                 __syncthreads();
@@ -2637,16 +2643,49 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         // node and carries no terminal multipliers; an optimum that satisfies the masked rows strictly
         // is the node's optimum.  Otherwise solve again with every row.
         const int first = (p.nT > 0 && p.lazy) ? 0 : 1;
-        for (int term_on = first; term_on < 2; term_on++) {
-            int its = 0;
-            S.term_on = term_on;
-            status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual);
-            if (term_on == 0) it1 = its; else it2 = its;
-            if (term_on == 0) {
+        if constexpr (!WARM) {
+            for (int term_on = first; term_on < 2; term_on++) {
+                int its = 0;
+                S.term_on = term_on;
+                status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, false);
+                if (term_on == 0) it1 = its; else it2 = its;
+                if (term_on == 0) {
+                    bool done = status == HMPC_INFEASIBLE;
+                    if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
+                    if (done) break;
+                    second = true; // the terminal-set rows are needed: the node is solved again with every row
+                }
+            }
+        } else {
+            // A parent whose optimum lies on terminal-set rows hands those down too: its set is first tried WITH the terminal
+            // rows (with them masked the point is far from the parent's, the hand-down drops out at once and a full first
+            // solve runs before the second one verifies).  Only an attempt (stage 2): if it does not verify the regular
+            // sequence -- masked first, so that an infeasible node's ray carries no terminal multipliers -- runs as without
+            // it.  Same steps as oracle/hsde_qp.c.
+            int stage = first;
+            if (wdual != nullptr && p.polish && first == 0) {
+                double m = 0.0;
+                for (int k = lane; k < p.nT; k += D::kNT) m = fmax(m, wdual[(T + 1) * nx + (T - 1) * p.nc + p.nc + k]);
+                if (block_max<D>(m, S.red, lane) > 0.0) stage = 2;
+            }
+            for (;;) { // (one call site: the solve is a large inlined body)
+                const int term_on = stage == 0 ? 0 : 1;
+                int its = 0;
+                S.term_on = term_on;
+                status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, stage == 2);
+                if (stage == 2) {
+                    if (status == HMPC_RETRY) { stage = 0; continue; }
+                    it1 = its;
+                    second = true;
+                    break;
+                }
+                if (term_on == 0) it1 = its; else it2 = its;
+                if (term_on == 1) break;
                 bool done = status == HMPC_INFEASIBLE;
                 if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
                 if (done) break;
-                second = true; // the terminal-set rows are needed: the node is solved again with every row
+                second = true;
+                stage = 1;
             }
         }
         __syncthreads();
