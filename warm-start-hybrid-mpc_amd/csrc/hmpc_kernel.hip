@@ -2653,9 +2653,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
                     bool done = status == HMPC_INFEASIBLE;
                     if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
                     if (done) break;
-                    second = true; // the terminal-set rows are needed: the node is solved again with every row
                 }
             }
+            // (HMPC_ITERS_TERMINAL is raised by the hand-down instantiations only: in this one the flag -- one more value
+            // alive across the inlined solve -- cost 6 % of every launch by register allocation alone, 666 k -> 625 k QP/s measured)
         } else {
             // A parent whose optimum lies on terminal-set rows hands those down too: its set is first tried WITH the terminal
             // rows (with them masked the point is far from the parent's, the hand-down drops out at once and a full first
@@ -2706,7 +2707,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         HMPC_CHK(status >= HMPC_OPTIMAL && status <= HMPC_NUMERICAL && tau > 0.0, 7);
 #endif
         if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0) | (handed ? HMPC_ITERS_HANDED : 0) |
-                                                     (second ? HMPC_ITERS_TERMINAL : 0);
+                                                     ((WARM && second) ? HMPC_ITERS_TERMINAL : 0);
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
         slot = S.flag[1];
