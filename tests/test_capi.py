@@ -88,3 +88,23 @@ def test_c_caller_gets_the_known_answers(tmp_path):
     exe = _build_c_example(tmp_path)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'c_abi_example: ok' in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_headline_kernel_keeps_its_register_budget(tmp_path):
+    # The one-wave-per-node kernel of the cart-pole shape lives at the edge of the register file (256 + 256 registers per
+    # lane, ~120 B of scratch): three times this round an edit that only added a flag or a branch elsewhere moved its
+    # register allocation and cost 6-8 % of every launch.  The scratch size of that instantiation, as the
+    # compiler reports it, is held here (cross-compiles without a GPU, ~15 s).
+    import re
+    import subprocess
+    csrc = os.path.join(ROOT, 'warm-start-hybrid-mpc_amd', 'csrc')
+    src = tmp_path / 'probe.hip'
+    src.write_text('#define HMPC_KERNEL_ONLY\n#include "hmpc_device.h"\n#include "hmpc_kernel.hip"\n'
+                   'template __global__ void hmpc_qp_kernel<4, 7, 4, 10, 3, 2, 1>(const DevProb, const double *, int, const int8_t *, int, '
+                   'const DevOut, double *, double *, const int32_t *, const DevWarm);\n')
+    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-Wno-pass-failed',
+                        '-I', os.path.join(ROOT, 'include'), '-I', csrc, '-c', str(src), '-o', str(tmp_path / 'probe.o'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+    assert scratch and max(scratch) <= 128, scratch
