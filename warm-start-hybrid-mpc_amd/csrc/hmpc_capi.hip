@@ -555,7 +555,8 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
             h->order_cap = B + B / 2;
         }
         order = h->order;
-        hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order);
+        hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order, w,
+                           (h->dp.T + 1) * h->dp.nx + (h->dp.T - 1) * h->dp.nc + h->dp.nc, h->dp.nT, h->dp.n_dual);
     }
     hipLaunchKernelGGL(w.index ? k.fn_warm : k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order, w);
