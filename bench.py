@@ -345,22 +345,6 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
             'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
             'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
         del fl
-    # (e) the same 1024 loops as several fleets, each on its own handle and host thread: the kernel of one fleet overlaps
-    # the host bookkeeping of the others (fleet.closed_loop_parallel)
-    from warm_start_hmpc_amd.fleet import closed_loop_parallel
-    K = 1024
-    errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
-    for parts in (2, 4):
-        progress('%d parallel fleets' % parts)
-        closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 2, errs[:, :2], parts=parts, frontier_width=8)           # warm-up
-        cold = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), 1, errs[:, :1], parts=parts, frontier_width=8)
-        st = closed_loop_parallel(ctrl, np.array([0., 0., 1., 0.]), steps + 1, errs, parts=parts, frontier_width=8)
-        dt = st['wall'] - cold['wall']
-        out['fleet_1024_loops_%d_handles' % parts] = {
-            'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
-            'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'handdown': True,
-            'launches_per_step_incl_cold_mean': st['rounds'] / (steps + 1.0) / parts,
-            'driver': '%d fleets of %d loops, one handle and one host thread each (fleet.closed_loop_parallel)' % (parts, K // parts)}
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
 
