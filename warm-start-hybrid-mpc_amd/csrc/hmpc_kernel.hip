@@ -2718,8 +2718,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
 // the order inside a bucket is whatever the atomics give -- a record does not depend on when its node is solved).
 // Launches with hand-down (warm.index set): a node whose PARENT needed the terminal-set rows goes first -- its own solve is
 // the long kind (up to two full solves when the handed-down set does not verify, ~5.6 ms against ~2 ms), and a long node
-// that starts late is the tail of the launch (measured on real trees: 11.8 ms per 4096 nodes with such nodes scattered);
-// the other handed-down nodes go last: three in four verify at once, short nodes fill the end of the launch.
+// that starts late is the tail of the launch (measured on real trees: 11.8 ms per 4096 nodes with such nodes scattered).
 // term_off: offset of the terminal-set multipliers in a dual row; nT of them.
 __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restrict__ fixg, int B, int nfix, int32_t *__restrict__ order,
                                                           const DevWarm warm, int term_off, int nT, int n_dual)
@@ -2737,7 +2736,6 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
                 bool any = false;
                 for (int k = 0; k < nT; k++) any = any || mu[k] > 0.0;
                 if (any) return 0; // (shares the bucket of the root-like nodes: first out)
-                return nb - 1;     // a handed-down node is most likely a short one (3 in 4 verify at once): last out
             }
         }
         const int8_t *f = fixg + (size_t)b * nfix;
