@@ -199,8 +199,11 @@ int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, const int32_t 
  * of all trees share kernel launches.  Needs hmpc_set_shift_maps.  Per loop and step:
  *     hmpc_fleet_solve : MIQP from x0[k] by branch and bound started from the loop's current tree (its root for a
  *                        cold loop), `width` candidates per tree and round (1 = the reference's node order);
- *                        speculation = k: descendants through the next k binaries ride in the launch of a
+ *                        speculation = k > 0: descendants through the next k binaries ride in the launch of a
  *                        node and are consumed only if the search gets there (same result, fewer launches);
+ *                        speculation < 0: dive prediction -- with a node whose parent's record is at hand, the rest of
+ *                        the dive predicted from the parent's rounded relaxed binaries and the sibling of every step
+ *                        ride along (2 (T nub - depth) nodes; for few loops: a cold start in a handful of launches);
  *                        cost[k] (+inf: infeasible, the loop stops), u0[k] (nu: applied input), x1[k] (nx: the
  *                        model's next state A x0 + B u0), solves[k], leaves[k]
  *     hmpc_fleet_shift : the tree becomes the warm start of the next step given the model error e0[k] of the step

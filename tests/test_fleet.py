@@ -57,6 +57,14 @@ def test_speculative_expansion_in_the_fleet_changes_launches_not_results():
     assert np.array_equal(spec['len_ws'], plain['len_ws']) and np.array_equal(spec['reopened'], plain['reopened'])
     assert np.max(np.abs(spec['nodes_ws'] - plain['nodes_ws'])) <= 4           # (kernel variant differs with the batch size)
     assert b.stats()['rounds'] < a.stats()['rounds'] / 2 and b.stats()['launched'] > a.stats()['launched']
+    # dive prediction (speculation < 0): the rest of a dive, predicted from the parent's rounded relaxed binaries, and the
+    # sibling of every step ride along -- linear in the depth; the cold start takes a handful of launches
+    c = FleetMPC(ctrl, 2)
+    dive = c.closed_loop(X0, 8, errors, frontier_width=1, speculation=-1, cold_speculation=-1)
+    np.testing.assert_allclose(dive['costs'], plain['costs'], rtol=1e-9, atol=1e-12)
+    assert np.array_equal(dive['len_ws'], plain['len_ws']) and np.array_equal(dive['reopened'], plain['reopened'])
+    assert np.max(np.abs(dive['nodes_ws'] - plain['nodes_ws'])) <= 4
+    assert c.stats()['rounds'] < a.stats()['rounds'] / 8
 
 
 def test_fleet_stops_a_loop_whose_miqp_is_infeasible_and_resets():

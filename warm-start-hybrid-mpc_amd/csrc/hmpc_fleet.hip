@@ -48,6 +48,7 @@ struct FleetTree {
     bool running = true;        // false once the MIQP of a step was infeasible (the loop has ended)
     std::vector<double> x0;     // state of the last solve
     std::unordered_map<std::string, FleetResult> cache; // key: the fixed prefix of the identifier
+    std::unordered_map<int32_t, std::vector<int8_t>> rounded; // dive prediction: a solved vertex node's relaxed binaries, rounded, by pool row
 };
 
 struct hmpc_fleet {
@@ -69,6 +70,8 @@ struct hmpc_fleet {
     double *d_lb = nullptr, *h_lb = nullptr, *d_lb_out = nullptr;
     uint8_t *d_flags = nullptr, *h_flags = nullptr;
     double *d_kx0 = nullptr, *d_ku0 = nullptr, *d_ke0 = nullptr, *h_k = nullptr; // K x nx, K x nu, K x nx (pinned: 3 blocks)
+    double *h_bits = nullptr;                                                  // dive prediction: primal rows of a round's nodes (pinned)
+    size_t cap_bits = 0;
     double *h_prow = nullptr, *d_prow = nullptr;                               // K primal rows: pinned / device (incumbents of a step)
     int32_t *h_inc = nullptr, *d_inc = nullptr;                                // K: pool row of each loop's incumbent
     long long rounds = 0, launched = 0, handed = 0;
@@ -231,6 +234,7 @@ extern "C" int hmpc_fleet_destroy(hmpc_fleet *f)
     if (f->h_k) (void)hipHostFree(f->h_k);
     if (f->h_prow) (void)hipHostFree(f->h_prow);
     if (f->h_inc) (void)hipHostFree(f->h_inc);
+    if (f->h_bits) (void)hipHostFree(f->h_bits);
     if (f->stream) (void)hipStreamDestroy(f->stream);
     delete f;
     return HMPC_OK;
@@ -259,6 +263,14 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
     if (f->broken) return fail(HMPC_EINVAL, "fleet: an earlier call failed midway; reset the fleet (hmpc_fleet_reset(f, -1)) first");
     struct Guard { hmpc_fleet *f; bool ok = false; ~Guard() { if (!ok) f->broken = true; } } guard{f};
     if (width < 1) width = 1;
+    // speculation < 0: DIVE PREDICTION (for few loops: it fetches the primal rows of every round).  A branch-and-bound dive
+    // follows the relaxation: where a parent's relaxed binaries round to, its descendants' mostly stay.  With a picked node
+    // whose parent's record is at hand, the whole predicted rest of the dive -- the node extended by the parent's rounded
+    // binaries, one more at a time -- and the sibling of every step ride in the same launch: 2 (T nub - depth) nodes, linear
+    // in the depth where the subtree expansion (speculation > 0) is exponential.  Results wait in the cache and are consumed
+    // only if and when the search selects those nodes: incumbent, leaves and solve counts are those of the search without it.
+    // A cold start is then the root, one launch with the predicted dive, and what the prediction missed.
+    const bool dive = speculation < 0;
     if (speculation < 0) speculation = 0;
     hmpc_handle *h = f->h;
     HIPCHK(hipSetDevice(h->device));
@@ -270,6 +282,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
         FleetTree &t = f->trees[k];
         t.ub = inf; t.inc = -1; t.inc_row = -1; t.solves = 0;
         t.cache.clear();
+        t.rounded.clear();
         std::memcpy(t.x0.data(), x0 + (size_t)k * nx, nx * sizeof(double));
     }
     std::vector<std::vector<int>> picks(K);
@@ -344,6 +357,25 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                         level.swap(next);
                         depth++;
                     }
+                    if (dive && t.wrow[i] >= 0) {
+                        auto pr = t.rounded.find(t.wrow[i]);
+                        if (pr != t.rounded.end()) {
+                            level.assign(fx, fx + nfix); // the predicted path, one binary more per step
+                            for (int j = t.depth[i]; j < nfix; j++) {
+                                for (int side = 0; side < 2; side++) { // the sibling of the step, then the step itself
+                                    level[j] = side == 0 ? (int8_t)(1 - pr->second[j]) : pr->second[j];
+                                    if (t.cache.count(key_of(level.data(), j + 1))) continue;
+                                    if (pass == 1) {
+                                        std::memcpy(f->h_fix + b * nfix, level.data(), nfix);
+                                        std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
+                                        f->h_widx[b] = -1; // (its parent rides in this very launch)
+                                        launch.push_back({k, j + 1});
+                                    }
+                                    b++;
+                                }
+                            }
+                        }
+                    }
                 }
             }
             B = b;
@@ -362,6 +394,17 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             HIPCHK(hipMemcpyAsync(f->h_obj, f->d_obj, B * sizeof(double), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpyAsync(f->h_status, f->d_status, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipMemcpyAsync(f->h_iters, f->d_iters, B * sizeof(int32_t), hipMemcpyDeviceToHost, f->stream));
+            if (dive) { // the round's primal rows: the rounded binaries of its vertex nodes predict their descendants' dives
+                if (B > f->cap_bits) {
+                    HIPCHK(hipStreamSynchronize(f->stream));
+                    if (f->h_bits) (void)hipHostFree(f->h_bits);
+                    f->h_bits = nullptr;
+                    f->cap_bits = 0;
+                    if (pin_alloc(&f->h_bits, 2 * B * p.n_primal)) return fail(HMPC_EDEVICE, "fleet: cannot allocate the prediction buffer");
+                    f->cap_bits = 2 * B;
+                }
+                HIPCHK(hipMemcpyAsync(f->h_bits, f->ppool + f->used * p.n_primal, B * p.n_primal * sizeof(double), hipMemcpyDeviceToHost, f->stream));
+            }
             HIPCHK(hipMemcpy2DAsync(f->h_nu, 2 * nfix * sizeof(double), rows + o_lb, p.n_dual * sizeof(double), 2 * nfix * sizeof(double), B,
                                     hipMemcpyDeviceToHost, f->stream));
             HIPCHK(hipStreamSynchronize(f->stream));
@@ -381,6 +424,12 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                 FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q),
                               f->h_status[q] == HMPC_OPTIMAL && (f->h_iters[q] & HMPC_ITERS_POLISHED) != 0, f->h_status[q] > 1};
                 f->handed += (f->h_iters[q] & HMPC_ITERS_HANDED) != 0;
+                if (dive && e.vertex && d < nfix) {
+                    std::vector<int8_t> bits(nfix);
+                    const double *u = f->h_bits + q * p.n_primal + (size_t)(p.T + 1) * nx;
+                    for (int j = 0; j < nfix; j++) bits[j] = u[(j / p.nub) * nu + p.nuc + (j % p.nub)] > 0.5 ? 1 : 0;
+                    f->trees[launch[q].k].rounded.emplace(e.row, std::move(bits));
+                }
                 f->trees[launch[q].k].cache.emplace(key_of(f->h_fix + q * nfix, d), e);
             }
             f->used += B;
