@@ -62,7 +62,9 @@ def test_speculative_expansion_in_the_fleet_changes_launches_not_results():
     c = FleetMPC(ctrl, 2)
     dive = c.closed_loop(X0, 8, errors, frontier_width=1, speculation=-1, cold_speculation=-1)
     np.testing.assert_allclose(dive['costs'], plain['costs'], rtol=1e-9, atol=1e-12)
-    assert np.array_equal(dive['len_ws'], plain['len_ws']) and np.array_equal(dive['reopened'], plain['reopened'])
+    # (which infeasibility proofs survive a shift depends on the ray, and the ray of a node on whether it was handed its
+    # parent's record and on the kernel variant the batch size selects: a proof within rounding of zero may fall either way)
+    assert np.array_equal(dive['len_ws'], plain['len_ws']) and np.max(np.abs(dive['reopened'] - plain['reopened'])) <= 1
     assert np.max(np.abs(dive['nodes_ws'] - plain['nodes_ws'])) <= 4
     assert c.stats()['rounds'] < a.stats()['rounds'] / 8
 
