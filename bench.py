@@ -327,21 +327,22 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
     # (d) the C++ fleet driver (hmpc_fleet_*, csrc/hmpc_fleet.hip): trees behind the handle, multiplier rows resident in
     # HBM, one call per step for all loops; same disturbances for every driver (sigma = 0.001, seed = loop index)
     from warm_start_hmpc_amd.fleet import FleetMPC
-    for K, spec, hand in ((1, 4, True), (1, -1, True), (1, 4, False), (64, 2, True), (256, 0, True), (1024, 0, True), (1024, 0, False)):
+    # (one loop: the cold start with dive prediction -- speculation < 0 --, warm steps with the subtree of the entering stage)
+    for K, spec, hand in ((1, 4, True), (1, 4, False), (64, 2, True), (256, 0, True), (1024, 0, True), (1024, 0, False)):
         errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in range(K)])
         progress('fleet of %d loops (hand-down %s)' % (K, hand))
         fl = FleetMPC(ctrl, K, handdown=hand)
-        width = 2 if spec < 0 else 8        # (dive prediction: a launch carries the whole predicted dive of every picked node)
-        fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], frontier_width=width, speculation=spec, cold_speculation=spec)   # warm-up (allocations)
-        cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], frontier_width=width, speculation=spec, cold_speculation=spec)
+        kw = dict(frontier_width=8, speculation=spec, cold_speculation=-1 if K == 1 else spec, cold_frontier_width=2 if K == 1 else 8)
+        fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], **kw)   # warm-up (allocations)
+        cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], **kw)
         s0 = fl.stats()
-        st = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, frontier_width=width, speculation=spec, cold_speculation=spec)
+        st = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, **kw)
         s1 = fl.stats()
         dt = st['wall'] - cold['wall']                                                            # subtract the cold-start step
-        out['fleet_%d_loops%s%s' % (K, '' if hand else '_no_handdown', '_dive_prediction' if spec < 0 else '')] = {
+        out['fleet_%d_loops%s' % (K, '' if hand else '_no_handdown')] = {
             'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
             'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'speculation_depth': spec,
-            'handdown': hand, 'handed_down_verified_per_step': (s1['handed'] - s0['handed']) / (K * (steps + 1.0)),
+            'cold_start': 'dive prediction' if K == 1 else 'as the warm steps', 'handdown': hand, 'handed_down_verified_per_step': (s1['handed'] - s0['handed']) / (K * (steps + 1.0)),
             'cold_step_ms': 1e3 * cold['wall'], 'warm_step_ms': 1e3 * dt / steps,
             'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
             'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}

@@ -71,7 +71,7 @@ class FleetMPC(object):
         return dict(rounds=r.value, launched=n.value, handed=v.value,
                     seconds=dict(zip(('select', 'stage', 'device', 'consume', 'shift'), [float(x) for x in t])))
 
-    def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0):
+    def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0, cold_frontier_width=None):
         """K closed loops from the same x0 under prescribed model errors (K, n_steps, nx) -- the shape of
         ``BatchedMPC.closed_loop(errors=...)``.  Returns dict: costs, nodes_ws, len_ws, reopened (K, n_steps; NaN / 0
         after a loop has ended), wall, steps, steps_per_sec."""
@@ -84,7 +84,8 @@ class FleetMPC(object):
         steps = 0
         tic = perf_counter()
         for t in range(n_steps):
-            r = self.solve(xs, frontier_width, speculation=cold_speculation if t == 0 else speculation)
+            r = self.solve(xs, (cold_frontier_width or frontier_width) if t == 0 else frontier_width,
+                           speculation=cold_speculation if t == 0 else speculation)
             ok = np.isfinite(r['cost'])
             cover, reopened = self.shift(errors[:, t])
             st['costs'][:, t] = r['cost']
