@@ -8,14 +8,17 @@ then -- when more than one rank runs -- all ranks exchange the incumbent upper
 bound with one RCCL all-reduce(min) of 8 bytes.  Frontier nodes are independent,
 so ranks hold disjoint shards and the scaling is weak (fixed work per GPU).
 
-The default frontier (``--frontier-kind real_tree``, SURVEY.md 8(d) C2 "replay
-frontier") is what a branch and bound actually solves: every node that
-cold-started searches from perturbed initial states solve, plus their leaves --
-about a third of them optimal, the rest infeasible -- each node once, cold (no
-hand-down from its parent: every record is what a stand-alone solve returns).
-``--frontier-kind random_prefix`` is the random-binary generator of the same
-section (p = 0.5: 98 % infeasible, the easy mix; p = 0.1); both, the hand-down
-variant and the other configs are secondary keys of the default run.
+The default frontier (``--frontier-kind real_tree``) is SURVEY.md 8(d) C2's
+"replay frontier" -- what a branch and bound actually solves: every node a
+cold-started search from x0 = [0, 0, 1, 0] solves plus its leaves, tiled to the
+frontier size; a third of the nodes optimal, the rest infeasible; each node
+solved cold (no hand-down from its parent: every record is what a stand-alone
+solve returns).  ``--states distinct`` takes the trees of distinct closed-loop
+states instead (x0 + 0.05 N(0,1) x_max per tree: 6 % of those nodes need the
+terminal set and are solved twice); ``--frontier-kind random_prefix`` is the
+random-binary generator of the same section (p = 0.5: 98 % infeasible, the easy
+mix; p = 0.1).  All of these, the hand-down variants and the other configs are
+secondary keys of the default run.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--frontier B]
 
@@ -173,13 +176,19 @@ def secondary_frontiers(ctrl, dev, x_max):
     T, nub = ctrl.T, ctrl.mld.nub
     x0_1 = np.array([0., 0., 1., 0.])
     out = {}
+    x0_n, fix_n, par_n = real_tree_frontier(ctrl, 4096, 0, x_max, spread=0.)
+    r, _ = _device_rate(ctrl.qp, x0_n, fix_n, dev, parent=par_n)
+    out['replay_frontier_4096_handdown'] = r               # the headline frontier, every node handed its parent's record
     x0_t, fix_t, par_t = real_tree_frontier(ctrl, 4096, 0, x_max)
+    r, _ = _device_rate(ctrl.qp, x0_t, fix_t, dev)
+    r['note'] = 'trees of distinct closed-loop states: 6 % of the nodes need the terminal set (two solves), the launch is as long as its tail (DESIGN.md 5)'
+    out['real_trees_distinct_states_4096'] = r
     r, _ = _device_rate(ctrl.qp, x0_t, fix_t, dev, parent=par_t)
-    out['real_trees_4096_handdown'] = r
-    r, _ = _device_rate(ctrl.qp, x0_t[:1024], fix_t[:1024], dev)
-    out['real_trees_1024_configs2_size'] = r
-    r, _ = _device_rate(ctrl.qp, x0_t[:1024], fix_t[:1024], dev, parent=np.where(par_t[:1024] < 1024, par_t[:1024], -1))
-    out['real_trees_1024_handdown'] = r
+    out['real_trees_distinct_states_4096_handdown'] = r
+    r, _ = _device_rate(ctrl.qp, x0_n[:1024], fix_n[:1024], dev)
+    out['replay_frontier_1024_configs2_size'] = r
+    r, _ = _device_rate(ctrl.qp, x0_n[:1024], fix_n[:1024], dev, parent=np.where(par_n[:1024] < 1024, par_n[:1024], -1))
+    out['replay_frontier_1024_handdown'] = r
     r, _ = _device_rate(ctrl.qp, x0_1, random_prefix_frontier(T, nub, 4096, p_one=0.5), dev)
     out['random_prefix_p0.5_4096'] = r
     r, _ = _device_rate(ctrl.qp, x0_1, random_prefix_frontier(T, nub, 4096, p_one=0.1), dev)
@@ -200,9 +209,9 @@ def secondary_frontiers(ctrl, dev, x_max):
         gen = make_controller('cart_pole_with_walls', backend='hip')
     finally:
         del os.environ['HMPC_FORCE_GENERIC']
-    r, _ = _device_rate(gen.qp, x0_t, fix_t, dev, reps=3, warm=1)
+    r, _ = _device_rate(gen.qp, x0_n, fix_n, dev, reps=3, warm=1)
     r['kernel'] = 'hmpc_qp_kernel<0,...> (run-time-sized: any MLD that fits LDS; HMPC_FORCE_GENERIC)'
-    out['real_trees_4096_generic_kernel'] = r
+    out['replay_frontier_4096_generic_kernel'] = r
     return out
 
 
@@ -353,9 +362,17 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
 
 def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05, x_center=None):
     """B nodes of real branch-and-bound trees: cold-started searches from x0 = [0, 0, 1, 0] + spread * N(0, 1) * x_max
-    (seed: rank, tree), every node they solve plus their leaves, until B nodes are collected.  Returns (x0 [B, nx],
-    fix [B, T nub], parent [B]: row of the node's parent in this frontier or -1)."""
+    (seed: rank, tree), every node they solve plus their leaves, until B nodes are collected; spread = 0: the one tree
+    of the nominal state, tiled (SURVEY 8(d) C2 as written).  Returns (x0 [B, nx], fix [B, T nub], parent [B]: row of the
+    node's parent in this frontier or -1)."""
     x_center = np.array([0., 0., 1., 0.]) if x_center is None else np.asarray(x_center, dtype=np.float64)
+    if spread == 0:
+        from helpers import real_tree_with_parents
+        fix1, par1 = real_tree_with_parents(ctrl, x_center, leaves_too=True, frontier_width=8)
+        reps = B // len(fix1) + 1
+        fix = np.tile(fix1, (reps, 1))[:B]
+        parent = np.concatenate([np.where(par1 >= 0, par1 + r * len(fix1), -1) for r in range(reps)])[:B].astype(np.int32)
+        return np.ascontiguousarray(np.repeat(x_center[None], B, axis=0)), np.ascontiguousarray(fix), parent
     from helpers import real_tree_with_parents
     xs, fixes, parents, n, j = [], [], [], 0, 0
     while n < B:
@@ -405,6 +422,8 @@ def main():
     ap.add_argument('--frontier', type=int, default=4096, help='nodes per GPU per step')
     ap.add_argument('--frontier-kind', default='real_tree', choices=('real_tree', 'random_prefix'),
                     help='real_tree: the nodes real searches solve (default); random_prefix: SURVEY 8(d) C2 generator with --p-one')
+    ap.add_argument('--states', default='nominal', choices=('nominal', 'distinct'),
+                    help='real_tree: the tree of x0 = [0, 0, 1, 0] tiled (SURVEY 8(d) C2), or the trees of distinct closed-loop states')
     ap.add_argument('--p-one', type=float, default=0.5)
     ap.add_argument('--handdown', action='store_true',
                     help='hand every node the record of its parent (hmpc_warm): the parents come from one untimed cold pass')
@@ -468,13 +487,14 @@ def main():
         ctrl = make_controller('cart_pole_with_walls', T=40 if args.workload == 'cart_pole_n40' else None, backend='hip', device=local)
         T, nub = ctrl.T, ctrl.mld.nub
         parent_h = None
+        spread = 0.05 if args.states == 'distinct' else 0.
         if args.frontier_kind == 'real_tree':
             if args.frontier_total > 0:    # strong scaling: ONE frontier, node k to rank k mod world (every rank builds it)
-                x0_all, fix_all, _ = real_tree_frontier(ctrl, args.frontier_total, 0, load_fixture('cart_pole_with_walls')['x_max'])
+                x0_all, fix_all, _ = real_tree_frontier(ctrl, args.frontier_total, 0, load_fixture('cart_pole_with_walls')['x_max'], spread=spread)
                 mine = shard(args.frontier_total, world, rank)
                 x0_h, fix_h = np.ascontiguousarray(x0_all[mine]), np.ascontiguousarray(fix_all[mine])
             else:                          # weak scaling: every rank its own trees (seeded by the rank)
-                x0_h, fix_h, parent_h = real_tree_frontier(ctrl, B, rank, load_fixture('cart_pole_with_walls')['x_max'])
+                x0_h, fix_h, parent_h = real_tree_frontier(ctrl, B, rank, load_fixture('cart_pole_with_walls')['x_max'], spread=spread)
         else:
             # disjoint shards: rank r takes seeds 1000 + r*B .. 1000 + (r+1)*B - 1 (strong scaling: of the one frontier)
             fix_h = random_prefix_frontier(T, nub, B, p_one=args.p_one, seed0=1000 + rank * B)
@@ -547,15 +567,17 @@ def main():
         # from the committed summary (profiles/collect.sh + profiles/summarise.py), valid for the default frontier
         traffic, traffic_src = None, None
         try:
-            if B == 4096 and args.frontier_kind == 'real_tree' and not args.handdown and args.workload == 'cart_pole_n20':
+            if B == 4096 and args.frontier_kind == 'real_tree' and args.states == 'nominal' and not args.handdown and args.workload == 'cart_pole_n20':
                 with open(os.path.join(ROOT, 'profiles', 'pmc_latest.json')) as fh:
                     traffic = json.load(fh)['hbm_traffic_bytes_per_launch']
                 traffic_src = 'profiles/pmc_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
         except (OSError, KeyError, ValueError):
             pass
         polished = int(((raw_iters >> 16) & 1).sum())
-        kind = ('nodes of real branch-and-bound trees (every node cold-started searches from perturbed states solve, plus their '
-                'leaves; SURVEY 8d C2 replay frontier)%s' % (', each handed its parent\'s record (hmpc_warm)' if warm is not None else ', each solved cold')
+        kind = ('%s%s' % ('replay frontier of SURVEY 8d C2: every node a cold-started search from x0 = [0, 0, 1, 0] solves plus its leaves, tiled'
+                          if args.states == 'nominal' else 'nodes of real trees from distinct closed-loop states (every node cold-started searches '
+                          'from [0, 0, 1, 0] + 0.05 N(0,1) x_max solve, plus their leaves)',
+                          ', each handed its parent\'s record (hmpc_warm)' if warm is not None else ', each solved cold')
                 if args.frontier_kind == 'real_tree' else 'random-prefix frontier (SURVEY 8d C2), p_one=%.2f' % args.p_one)
         line = {
             'metric': 'QP subproblems/sec, cart-pole-with-walls N=20 synthetic frontier' if args.workload == 'cart_pole_n20' else 'QP subproblems/sec, ' + args.workload,
@@ -565,7 +587,8 @@ def main():
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': ('cart_pole_with_walls N=%d, 4 binaries/step, %s' % (T, kind))
                        if args.workload != 'random_mld' else 'random MLD nx=20 nu=6+8 N=30 (SURVEY 8d C4), dive frontier',
-                       'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist() if x0_h.ndim == 1 else 'one initial state per tree: [0, 0, 1, 0] + 0.05 N(0,1) x_max',
+                       'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist() if x0_h.ndim == 1 else ([0., 0., 1., 0.] if args.states == 'nominal' and args.frontier_kind == 'real_tree'
+                                                                                                     else 'one initial state per tree: [0, 0, 1, 0] + 0.05 N(0,1) x_max'),
                        'parallelism': 'frontier sharded by node, '
                        'one RCCL all-reduce(min) of the incumbent per step' if world > 1 else 'single GPU',
                        'solver': 'HSDE interior point + Riccati, tol 1e-8, lazy terminal set, <= 2 refinement steps, active-set polish'},
