@@ -435,6 +435,7 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 #ifndef POLISH_ROUNDS_WARM
 #define POLISH_ROUNDS_WARM 3     /* active sets tried when the set is handed down by the parent node */
 #endif
+#define POLISH_WARM_BMOVE 0.5 /* a hand-down is not tried where a fixed binary lies further than this from the parent's value */
 #ifndef POLISH_WARM_VMAX
 #define POLISH_WARM_VMAX 1e-2
 #endif
@@ -605,7 +606,14 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
         for (int t = 0; t <= T; t++) for (int i = 0; i < nx; i++) k->w[t * nz + i] = wprimal[t * nx + i];
         for (int t = 0; t < T; t++) for (int i = 0; i < nu; i++) k->w[t * nz + nx + i] = wprimal[(T + 1) * nx + t * nu + i];
         for (int i = 0; i < nx; i++) k->w[i] = x0[i];
-        for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) k->w[t * nz + nx + nuc + b] = fix[t * nub + b];
+        /* a binary this node fixes far from where the parent's relaxation had it (the 1-branch of a binary relaxed to 0:
+         * most infeasible children): the parent's set is not near this node's optimum, nothing is tried */
+        double bmove = 0;
+        for (int t = 0; t < T; t++) for (int b = 0; b < nub; b++) if (fix[t * nub + b] >= 0) {
+            const double d = fabs(k->w[t * nz + nx + nuc + b] - fix[t * nub + b]);
+            if (d > bmove) bmove = d;
+            k->w[t * nz + nx + nuc + b] = fix[t * nub + b];
+        }
         for (int i = 0; i < n; i++) if (fabs(k->w[i]) > winf0) winf0 = fabs(k->w[i]);
         for (int t = 0; t < T; t++) {
             int m = mt(p, t), mg = m - 2 * nub, ro = p->roff[t]; const double *sc = t < T - 1 ? p->sreg : p->slast;
@@ -620,7 +628,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             }
         }
         for (int i = 0; i < (T + 1) * nx; i++) if (fabs(wdual[i]) * p->cs > zinf0) zinf0 = fabs(wdual[i]) * p->cs;
-        if (winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
+        if (bmove <= POLISH_WARM_BMOVE && winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
         if (attempt_only) return -1; /* (the caller goes on with the regular sequence of solves) */
         memset(k->w, 0, sizeof(double) * n);
         for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;

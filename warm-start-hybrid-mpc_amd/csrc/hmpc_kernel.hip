@@ -48,6 +48,7 @@
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
+#define HMPC_POLISH_WARM_BMOVE 0.5 // a hand-down is not tried where a fixed binary lies further than this from the parent's value
 #define HMPC_POLISH_WARM_VMAX 1e-2 // a handed-down set whose point misses an inactive row by more is dropped at once
 #ifndef HMPC_KERNEL_ATTR
 #define HMPC_KERNEL_ATTR
@@ -1782,6 +1783,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             S.w[o] = j < nx ? wprim[t * nx + j] : wprim[(T + 1) * nx + t * nu + (j - nx)];
         }
         __syncthreads();
+        // a binary this node fixes far from where the parent's relaxation had it (the 1-branch of a binary relaxed to 0: most
+        // infeasible children): the parent's set is not near this node's optimum, nothing is tried
+        double bmove = 0.0;
+        for (int o = lane; o < T * nub; o += D::kNT)
+            if (S.fix[o] >= 0) bmove = fmax(bmove, fabs(S.w[(o / nub) * nz + nx + nuc + (o % nub)] - (double)S.fix[o]));
+        bmove = block_max<D>(bmove, S.red, lane);
         set_prescribed<D>(p, S, lane, 1.0);
         __syncthreads();
         const int o_mu = (T + 1) * nx, o_lb = o_mu + (T - 1) * p.nc + p.ncL, o_ub = o_lb + T * nub;
@@ -1812,7 +1819,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             block_reduce<D, 2>(v, op, S.red, lane);
             winf = v[0]; zinf = v[1];
         }
-        if (winf == winf && zinf == zinf) { mode = 1; warm_try = true; }
+        if (winf == winf && zinf == zinf && bmove <= HMPC_POLISH_WARM_BMOVE) { mode = 1; warm_try = true; }
         else { // (a parent record that is not a finite point: nothing to hand down)
             ROWS_BEGIN(k, rw)
                 if (R.D(k, rw.e) != 0.0) R.z(k, rw.e) = 1.0;
@@ -1822,6 +1829,11 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             set_prescribed<D>(p, S, lane, tau);
         }
         __syncthreads();
+        if (attempt_only && !warm_try) { // (nothing to try: the caller runs the regular sequence of solves)
+            iters = 0;
+            tau_out = tau;
+            return HMPC_RETRY;
+        }
     }
     for (it = 0; it <= p.max_iter;) {
       if (mode == 0) {
