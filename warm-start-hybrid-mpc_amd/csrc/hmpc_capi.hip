@@ -286,6 +286,39 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     do {
         if ((rc = upload_stage(h, reg, p.reg))) break;
         if ((rc = upload(h, reg.C, &p.Creg))) break;
+        {
+            // dense / singleton split of the stage rows (generic kernel)
+            std::vector<int> drow, rinfo(p.mreg, 0), sptr(nz + 1, 0), srow;
+            std::vector<double> sval(p.mreg, 0.0);
+            for (int r = 0; r < p.mreg; r++) {
+                int cnt = 0, col = 0;
+                for (int j = 0; j < nz; j++)
+                    if (reg.C[(size_t)r * nz + j] != 0.0) { cnt++; col = j; }
+                if (cnt >= 2) { rinfo[r] = -((int)drow.size() + 1); drow.push_back(r); }
+                else { rinfo[r] = col; sval[r] = reg.C[(size_t)r * nz + col]; }
+            }
+            p.nd = (int)drow.size();
+            p.ndp = (p.nd + 3) / 4 * 4;
+            std::vector<double> Cdn((size_t)p.ndp * nz, 0.0);
+            for (int k = 0; k < p.nd; k++)
+                for (int j = 0; j < nz; j++) Cdn[(size_t)k * nz + j] = reg.C[(size_t)drow[k] * nz + j];
+            drow.resize(p.ndp, 0);
+            for (int j = 0; j < nz; j++) {
+                for (int r = 0; r < p.mreg; r++)
+                    if (rinfo[r] == j && sval[r] != 0.0) srow.push_back(r);
+                sptr[j + 1] = (int)srow.size();
+            }
+            p.ns = (int)srow.size();
+            if (Cdn.empty()) Cdn.push_back(0.0);
+            if (drow.empty()) drow.push_back(0);
+            if (srow.empty()) srow.push_back(0);
+            if ((rc = upload(h, Cdn, &p.Cdn))) break;
+            if ((rc = upload(h, drow, &p.drow))) break;
+            if ((rc = upload(h, rinfo, &p.rinfo))) break;
+            if ((rc = upload(h, sval, &p.sval))) break;
+            if ((rc = upload(h, sptr, &p.sptr))) break;
+            if ((rc = upload(h, srow, &p.srow))) break;
+        }
         if ((rc = upload(h, ccv, &p.ccv))) break;
         if ((rc = upload(h, cci, &p.cci))) break;
         if ((rc = upload(h, vec(q->F, (size_t)q->nc * nx), &p.F_raw))) break;
@@ -314,10 +347,11 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     const size_t lds_cu = 160 * 1024;
     if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
     // generic kernel on the matrix cores (nz >= 16): the dense stage rows go to LDS if they fit beside everything else
-    p.dense_c_lds = 0;
+    p.split_lds = 0;
     if (p.nz >= 16) {
         const bool big = hmpc_lds_bytes(p, 0, 0) > lds_cu || getenv("HMPC_FORCE_BIG");
-        if (hmpc_lds_bytes(p, 0, big ? 1 : 0) + (size_t)p.mreg * p.nz * sizeof(double) <= lds_cu) p.dense_c_lds = 1;
+        p.split_lds = 1;
+        if (hmpc_lds_bytes(p, 0, big ? 1 : 0) > lds_cu) p.split_lds = 0;
     }
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
@@ -706,6 +740,7 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
                 for (int k = 0; k < 8; k++)
                     fprintf(stderr, "hip stamps ph %d %-22s %12.0f cycles %5.1f%%\n", ph, names[k], tr[2 * 64 * 8 + ph * 8 + k], 100 * tr[2 * 64 * 8 + ph * 8 + k] / tot);
         }
+        // (the generic kernel's solve stamps its phases as: 6 g = C'e, 7 both sweeps, 8 lam, 9 dz, 10 nu of the fixed binaries)
         const char *fn[11] = {"F gram+PA", "F assemble col", "F prescribe", "F eliminate", "F writeback+sync", "F Minv", "S g=C'e", "S backward", "S Minv*mu", "S forward", "S lam,dz,dnuf"};
         for (int k = 0; k < 11; k++)
             if (tr[2 * 64 * 8 + 16 + k] > 0) fprintf(stderr, "hip fine   %-22s %12.0f cycles\n", fn[k], tr[2 * 64 * 8 + 16 + k]);

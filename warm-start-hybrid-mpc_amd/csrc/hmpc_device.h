@@ -38,7 +38,16 @@ struct DevProb {
     unsigned *check_flag;                      // diagnostic build (HMPC_CHECK): bits raised by failed in-kernel checks; follows work_counter
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
-    int dense_c_lds;                           // generic kernel: the dense stage rows are staged in LDS (they fit beside the rest)
+    // generic kernel, nz >= 16: the stage rows split into DENSE rows (two or more nonzeros: matrix-core contractions and
+    // dense products) and SINGLETON rows (one nonzero -- bounds; they only touch the diagonal of C'DC and one component
+    // of a product), staged in LDS when they fit beside the rest (split_lds)
+    int nd, ndp, ns;                           // dense rows, the same padded to a multiple of 4 (zero rows), singleton rows
+    const double *Cdn;                         // ndp x nz
+    const int *drow;                           // ndp: local row of dense row k (padding: row 0, zero coefficients)
+    const int *rinfo;                          // mreg: singleton row -> its column; dense row k -> -(k + 1)
+    const double *sval;                        // mreg: coefficient of a singleton row
+    const int *sptr, *srow;                    // singleton rows by column: sptr[nz + 1], srow[ns]
+    int split_lds;
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
     const double *A, *B, *P, *PT, *Q, *R, *QT; // P = 2 cs (Q'Q (+) R'R), PT = 2 cs QT'QT
@@ -95,7 +104,10 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
         d += 2 * (size_t)p.nnz0;                                          // rval0 cval0
         i += (p.mreg + 1) + p.nnz0 + (nz + 1) + p.nnz0;                   // rptr0 rcol0 cptr0 crow0
     }
-    if (kc == 0 && p.dense_c_lds) d += (size_t)p.mreg * nz;                 // dense stage rows for the matrix-core contractions
+    if (kc == 0 && p.split_lds) {                                          // split stage rows (dense block, singleton lists)
+        d += (size_t)p.ndp * nz + p.mreg;
+        i += (size_t)p.ndp + p.mreg + (nz + 1) + p.ns;
+    }
     if (big) d += lms;                                                     // one stage's multipliers staged for the sweeps
     return d * sizeof(double) + i * sizeof(int) + b;
 }

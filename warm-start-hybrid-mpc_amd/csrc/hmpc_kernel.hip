@@ -223,7 +223,10 @@ struct Lds {
     ListsG G0;         // the same lists left in global memory, and the Riccati factor in a global slab:
     double *LmG, *PrG; //   the streaming variant for problems whose factor does not fit in LDS (Dims::kBig)
     ldsd *Ls;          //   ... and one stage's multipliers staged in LDS for the sweeps of a solve
-    const ldsd *Cd;    // generic kernel: the stage rows as a dense mreg x nz matrix for the matrix-core contractions (null: read p.Creg)
+    // generic kernel, nz >= 16 (DevProb::split_lds; Cdn null otherwise): dense stage rows (ndp x nz), their local rows,
+    // per row: singleton column or -(dense index + 1), singleton coefficient; singleton rows by column
+    const ldsd *Cdn, *sval;
+    const ldsi *drow, *rinfo, *sptr, *srow;
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
@@ -390,9 +393,11 @@ template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, c
     if constexpr (D::kBig) {
         // streaming form with the dense stage rows in LDS: a dense product there beats a list walk in global memory
         // (two dependent loads per term at L2 latency)
-        if (S.Cd && lr < p.mreg) {
+        if (S.Cdn && lr < p.mreg) {
             const int nz = D::nz(p);
-            const ldsd *c = S.Cd + lr * nz;
+            const int ri = S.rinfo[lr];
+            if (ri >= 0) return S.sval[lr] * v[ri]; // singleton row
+            const ldsd *c = S.Cdn + (-ri - 1) * nz;
             double a0 = 0, a1 = 0;
             int j = 0;
             for (; j + 2 <= nz; j += 2) {
@@ -441,16 +446,20 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
             }
         }
         a = a0 + a1;
-    } else if (D::kBig && S.Cd) {
+    } else if (D::kBig && S.Cdn) {
         const int nz = D::nz(p);
-        const ldsd *eb = base + t * p.mreg, *c = S.Cd + j;
+        const ldsd *eb = base + t * p.mreg, *c = S.Cdn + j;
         double a0 = 0, a1 = 0;
         int r = 0;
-        for (; r + 2 <= p.mreg; r += 2) {
-            a0 += c[r * nz] * eb[r];
-            a1 += c[(r + 1) * nz] * eb[r + 1];
+        for (; r + 2 <= p.nd; r += 2) { // dense rows
+            a0 += c[r * nz] * eb[S.drow[r]];
+            a1 += c[(r + 1) * nz] * eb[S.drow[r + 1]];
         }
-        if (r < p.mreg) a0 += c[r * nz] * eb[r];
+        if (r < p.nd) a0 += c[r * nz] * eb[S.drow[r]];
+        for (int k = S.sptr[j]; k < S.sptr[j + 1]; k++) { // singleton rows of this column
+            const int sr = S.srow[k];
+            a1 += S.sval[sr] * eb[sr];
+        }
         a = a0 + a1;
     } else {
         a = col_dot(stage_lists<D>(S), j, base + t * p.mreg);
@@ -728,9 +737,14 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 #define LM_U(nx, nu, i, j) ((nx) * (nu) + (i) * ((i) - 1) / 2 + (j)) /* input row i, pivot j < i */
 
 template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, int lane, int t, const ldsd *Pn, int pns);
+template <class D> DEV bool factor_tiles_fits(const DevProb &p);
+template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS);
 
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
+    if constexpr (D::kNT == 4 * WAVE) {
+        if (factor_tiles_fits<D>(p) && !DBG_SKIP(4)) return factor_tiles<D>(p, S, lane FSTAMP_PASS);
+    }
     FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
@@ -909,12 +923,7 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
         while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
         const int tj = q - ti * (ti + 1) / 2;
         mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-        if (S.Cd)
-            acc = mfma_tile(wl, p.mreg,
-                            [&](int r, int k) { const int i = ti * 16 + r; const double v = S.Cd[k * nz + (i < nz ? i : nz - 1)] * Dt[k]; return i < nz ? v : 0.0; },
-                            [&](int k, int c) { const int j = tj * 16 + c; const double v = S.Cd[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
-        else
-            acc = mfma_tile(wl, p.mreg,
+        acc = mfma_tile(wl, p.mreg,
                             [&](int r, int k) { const int i = ti * 16 + r; const double v = p.Creg[(size_t)k * nz + (i < nz ? i : nz - 1)] * Dt[k]; return i < nz ? v : 0.0; },
                             [&](int k, int c) { const int j = tj * 16 + c; const double v = p.Creg[(size_t)k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         if (term) {
@@ -938,6 +947,274 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
         }
     }
     __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// The factorisation of the run-time-sized kernel with four waves per node and 16 <= nz <= 64 (BASELINE configs[4]): the
+// stage matrix never leaves the registers it is computed in.  The lower-triangle 16 x 16 tiles of
+//   M = P + C' D C + [A B]' P_{t+1} [A B]
+// are dealt to the waves (tile q to wave q mod 4, at most three per wave); a lane holds the four entries of a tile the
+// matrix-core instruction returns to it (rows (l >> 4) + 4 r of column l & 15) and keeps them through the elimination:
+// per pivot the owners of the pivot column (lower triangle: column pj below the diagonal, row pj left of it) publish it
+// in LDS, ONE LDS-only barrier, and every lane updates its own entries from the five values it needs per tile.  The
+// operands of the contractions are fetched in batches (all loads of five steps in flight before the first product).
+// The LDS form above (dense M in LDS, every entry read, updated and written back per pivot, index arithmetic per
+// entry) took 58 k cycles per stage on configs[4], this one [measured below in DESIGN 4.2].
+// What the stage leaves behind is what the LDS form leaves: multipliers, reciprocal pivots, P_t, mb.
+// ---------------------------------------------------------------------------------------------
+template <int NB, class FA, class FB> DEV mfma_d4 mfma_tile_batched(int wl, int K, FA a, FB b, mfma_d4 acc)
+{
+    const int r = wl & 15, kq = wl >> 4;
+    int k0 = 0;
+    for (; k0 + 4 * NB <= K; k0 += 4 * NB) {
+        double av[NB], bv[NB];
+#pragma unroll
+        for (int s = 0; s < NB; s++) { av[s] = a(r, k0 + 4 * s + kq); bv[s] = b(k0 + 4 * s + kq, r); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NB; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+    }
+    if (k0 < K) { // the last, partial batch: clamped indices, zeroed operands (a read under a lane predicate waits for itself)
+        double av[NB], bv[NB];
+#pragma unroll
+        for (int s = 0; s < NB; s++) {
+            const int k = k0 + 4 * s + kq, kc = k < K ? k : K - 1;
+            const double x = a(r, kc), y = b(kc, r);
+            av[s] = k < K ? x : 0.0;
+            bv[s] = k < K ? y : 0.0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NB; s++)
+            if (k0 + 4 * s < K) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <class D> DEV bool factor_tiles_fits(const DevProb &p)
+{
+    const int nz = D::nz(p);
+    return D::kNT == 4 * WAVE && nz >= 16 && nz <= 64 && p.mreg < 65536;
+}
+
+template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
+{
+    FSTAMP_DECL;
+    constexpr int MQ = 3; // tiles per wave: nz <= 64 -> 10 lower-triangle tiles over four waves
+    const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
+    const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
+    const int wl = lane & 63, wave = __builtin_amdgcn_readfirstlane(lane >> 6), r0 = wl >> 4, c0 = wl & 15; // (wave: uniform, so that everything per tile is scalar)
+    const int tn = (nz + 15) >> 4, tx = (nx + 15) >> 4, ntile = tn * (tn + 1) / 2;
+    ldsd *Mf = S.Mm;           // the matrix as the other lanes see it: dense nz x nz, both triangles
+    ldsd *dump = S.red + 39;   // where the entries of a tile that overhang the matrix are written
+    // this lane's entries: tile qq -> rows row0[qq] + 4 r, column colq[qq]
+    int row0[MQ], colq[MQ];
+    bool have[MQ], offd[MQ], ownw[MQ], mirw[MQ];
+    int lastrow[MQ], lastcol[MQ];
+    ldsd *wp[MQ][4], *mp[MQ][4]; // where entry (qq, r) and its mirror image live in Mf
+#pragma unroll
+    for (int qq = 0; qq < MQ; qq++) {
+        const int q = wave + 4 * qq;
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
+        const int tj = q - ti * (ti + 1) / 2;
+        have[qq] = q < ntile;
+        offd[qq] = have[qq] && ti != tj;
+        // between two pivots only the rows of inputs still to be eliminated are read by other lanes: a tile is written
+        // back where its rows (its mirror image: its columns) reach into them
+        lastrow[qq] = ti * 16 + 15;
+        lastcol[qq] = tj * 16 + 15;
+        ownw[qq] = have[qq] && lastrow[qq] >= nx;
+        mirw[qq] = offd[qq] && lastcol[qq] >= nx;
+        row0[qq] = ti * 16 + r0;
+        colq[qq] = tj * 16 + c0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = row0[qq] + 4 * r, col = colq[qq];
+            const bool ok = have[qq] && row < nz && col < nz;
+            wp[qq][r] = ok ? Mf + row * nz + col : dump;
+            mp[qq][r] = ok ? Mf + col * nz + row : dump;
+        }
+    }
+    for (int e = lane; e < nx * nx; e += D::kNT) {
+        const int i = e / nx, j = e - i * nx;
+        if (i >= j) fac_pr<D>(S)[T * nxs + sym(i, j)] = S.PT[e];
+    }
+    int bad = 0;
+    for (int t = T - 1; t >= 0; t--) {
+        const ldsd *Pn = t == T - 1 ? S.PT : Mf; // P_{t+1}: the terminal Hessian, or the block the previous stage left
+        const int pns = t == T - 1 ? nx : nz;
+        const ldsi *fx = S.fix + t * nub;
+        const auto Lm = fac_lm<D>(S) + t * lms;
+        int nfixed = 0;
+        for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
+        // diagonal of C' D C from the singleton rows (S.mv is free during a factorisation), read after the barrier below
+        if (S.Cdn && lane < nz) {
+            const ldsd *Dq = S.e + t * p.mreg;
+            double a = 0;
+            for (int k = S.sptr[lane]; k < S.sptr[lane + 1]; k++) {
+                const int sr = S.srow[k];
+                const double c = S.sval[sr];
+                a += c * c * Dq[sr];
+            }
+            S.mv[lane] = a;
+        }
+        // (1) PA = P_{t+1} [A B]  (nx x nz)
+        for (int q = wave; q < tx * tn; q += D::kNW) {
+            const int ti = q / tn, tj = q - ti * tn;
+            const int i = ti * 16 + c0, ic = i < nx ? i : nx - 1, j = tj * 16 + c0, jc = j < nz ? j : nz - 1;
+            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = mfma_tile_batched<5>(wl, nx,
+                                       [&](int, int k) { const double v = Pn[ic * pns + k]; return i < nx ? v : 0.0; },
+                                       [&](int k, int) { const double v = S.AB[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int ii = ti * 16 + r0 + 4 * r;
+                if (ii < nx && j < nz) S.PA[ii * nz + j] = acc[r];
+            }
+        }
+        lds_barrier();
+        // (2) the tiles of M, in registers
+        double m[MQ][4];
+        const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
+        const bool term = S.term_on && t == T - 1;
+#pragma unroll
+        for (int qq = 0; qq < MQ; qq++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) m[qq][r] = 0.0;
+            if (have[qq]) {
+                const int i = row0[qq] - r0 + c0, ic = i < nz ? i : nz - 1; // A operand: row l & 15 of the tile's rows
+                const int j = colq[qq], jc = j < nz ? j : nz - 1;
+                const double sdg = S.Cdn ? S.mv[jc] : 0.0;
+                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                if (S.Cdn) // the dense rows; the singleton rows only reach the diagonal (sdg)
+                    acc = mfma_tile_batched<4>(wl, p.ndp,
+                                               [&](int, int k) { const double v = S.Cdn[k * nz + ic] * Dt[S.drow[k]]; return i < nz ? v : 0.0; },
+                                               [&](int k, int) { const double v = S.Cdn[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                else
+                    acc = mfma_tile_batched<5>(wl, p.mreg,
+                                               [&](int, int k) { const double v = p.Creg[(size_t)k * nz + ic] * Dt[k]; return i < nz ? v : 0.0; },
+                                               [&](int k, int) { const double v = p.Creg[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                if (term) {
+                    const ldsd *De = S.e + p.Toff;
+                    acc = mfma_tile_batched<5>(wl, p.nT,
+                                               [&](int, int k) { const double v = p.Ct[(size_t)k * nz + ic] * De[k]; return i < nz ? v : 0.0; },
+                                               [&](int k, int) { const double v = p.Ct[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                }
+                acc = mfma_tile_batched<5>(wl, nx,
+                                           [&](int, int k) { const double v = S.AB[k * nz + ic]; return i < nz ? v : 0.0; },
+                                           [&](int k, int) { const double v = S.PA[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = row0[qq] + 4 * r, rc = row < nz ? row : nz - 1;
+                    m[qq][r] = acc[r] + S.P[rc * nz + jc] + (row == j ? sdg : 0.0);
+                }
+            }
+        }
+        // every lane writes all its entries, no predicate: the addresses were fixed once (overhang -> dump slot)
+        auto publish = [&]() {
+#pragma unroll
+            for (int qq = 0; qq < MQ; qq++) {
+                if (have[qq]) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *wp[qq][r] = m[qq][r];
+                    if (offd[qq]) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) *mp[qq][r] = m[qq][r];
+                    }
+                }
+            }
+        };
+        publish(); // (P_{t+1} in Mf was last read in (1), before the barrier every wave has passed)
+        FSTAMP(0);
+        // (3) fixed binaries: mb = sum of the columns of the binaries fixed to one, then identity rows / columns
+        ldsd *Lw;
+        if constexpr (D::kBig) Lw = S.Ls;
+        else Lw = S.Lm + t * lms;
+        for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
+        if (nfixed) {
+            const int b0 = nx + nuc;
+            lds_barrier();
+            for (int i = lane; i < nz; i += D::kNT) {
+                double a = 0;
+                for (int b = 0; b < nub; b++)
+                    if (fx[b] == 1) a += Mf[i * nz + b0 + b];
+                S.g[t * nz + i] = a;
+            }
+#pragma unroll
+            for (int qq = 0; qq < MQ; qq++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = row0[qq] + 4 * r, col = colq[qq];
+                    const bool fi = row >= b0 && row < nz && fx[row - b0] >= 0;
+                    const bool fj = col >= b0 && col < nz && fx[col - b0] >= 0;
+                    if (fi || fj) m[qq][r] = (row == col) ? 1.0 : 0.0;
+                }
+            }
+            lds_barrier();
+            publish();
+        } else {
+            for (int i = lane; i < nz; i += D::kNT) S.g[t * nz + i] = 0.0;
+        }
+        FSTAMP(2);
+        // (4) elimination of the inputs: per pivot, read the pivot row from Mf, update the registers, write them back
+        for (int j = 0; j < nu; j++) {
+            if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot: the solves skip it as well
+                if (lane == 0) S.dinv[t * nu + j] = 1.0;
+                continue;
+            }
+            const int pj = nx + j;
+            const ldsd *v = Mf + pj * nz;
+            lds_barrier(); // the entries written after the previous step are visible
+            const double d = v[pj];
+            if (!(d > 0.0)) bad = 1;
+            double rinv = __builtin_amdgcn_rcp(d);
+            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
+#pragma unroll
+            for (int qq = 0; qq < MQ; qq++) {
+                if (have[qq]) {
+                    const double vc = v[colq[qq]]; // (an index past nz reads inside the scratch block; the entry is never used)
+                    double vr[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) vr[r] = v[row0[qq] + 4 * r];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) m[qq][r] -= (vr[r] * rinv) * vc;
+                }
+            }
+            if (lane < nz && (lane < nx || lane > pj))
+                Lw[lane < nx ? LM_X(nx, nu, lane, j) : LM_U(nx, nu, lane - nx, j)] = v[lane] * rinv;
+            if (lane == 0) S.dinv[t * nu + j] = rinv;
+            lds_barrier(); // every lane has read the pivot row
+#pragma unroll
+            for (int qq = 0; qq < MQ; qq++) {
+                if (ownw[qq] && lastrow[qq] > pj) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *wp[qq][r] = m[qq][r];
+                }
+                if (mirw[qq] && lastcol[qq] > pj) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *mp[qq][r] = m[qq][r];
+                }
+            }
+        }
+        publish(); // all of it: the leading block is P_t, read by the next stage's product
+        FSTAMP(3);
+        // (5) P_t: the leading block of Mf for the next stage's product, packed for the solves
+#pragma unroll
+        for (int qq = 0; qq < MQ; qq++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = row0[qq] + 4 * r, col = colq[qq];
+                if (have[qq] && row < nx && col <= row) fac_pr<D>(S)[t * nxs + sym(row, col)] = m[qq][r];
+            }
+        }
+        lds_barrier();
+        if constexpr (D::kBig)
+            for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e];
+        FSTAMP(4);
+    }
+    __syncthreads(); // (the slab is read by other threads than wrote it: this barrier covers global memory)
+    return bad ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1320,8 +1597,9 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
 
 template <class D, int RS, class RM>
 DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
-                   const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf)
+                   const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
+    FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     for (int o = lane; o < T * nz; o += D::kNT) {
@@ -1332,7 +1610,9 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     for (int j = lane; j < nx; j += D::kNT) S.pv[T * nx + j] = -(gsrc ? gs * gsrc[T * nz + j] : 0.0);
     __syncthreads();
     const bool wave_sweeps = nz <= WAVE && (!D::kBig || lms <= 8 * (D::kNT > WAVE ? D::kNT - WAVE : D::kNT));
+    FSTAMP(6);
     if (wave_sweeps) kkt_sweeps_wave<D>(p, S, lane, usex0, csrc, cs, useb, dw);
+    FSTAMP(7);
     // backward sweep (barrier form: stage vectors wider than a wave)
     for (int t = wave_sweeps ? -1 : T - 1; t >= 0; t--) {
         const auto Lm = fac_lm<D>(S) + t * lms;
@@ -1416,6 +1696,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         for (int l = 0; l < nx; l++) a += fac_pr<D>(S)[t * nxs + sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
+    FSTAMP(8);
     {
         const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
         ROWS_BEGIN(k, rw)
@@ -1425,6 +1706,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         ROWS_END
     }
     __syncthreads();
+    FSTAMP(9);
     // multipliers of the fixed binaries from the stationarity row of their component
     const bool own_g = gsrc && gsrc != S.g; // a refinement call passes its residual in S.g (zero there)
     for (int o = lane; o < T * nub; o += D::kNT) {
@@ -1440,6 +1722,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         dnuf[o] = a;
     }
     __syncthreads();
+    FSTAMP(10);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1673,7 +1956,7 @@ DEV void kkt_dispatch(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm,
                       const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
 {
     if constexpr (D::kNX > 0) kkt_solve_reg<D, RS>(p, S, R, rm, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
-    else kkt_solve<D, RS>(p, S, R, rm, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf);
+    else kkt_solve<D, RS>(p, S, R, rm, lane, gsrc, gs, usex0, csrc, cs, useb, dw, dlam, dnuf FSTAMP_PASS);
 }
 
 // f'y + h'z of a direction / iterate (lam_0, multipliers of binaries fixed to one, row multipliers in zrow)
@@ -2555,7 +2838,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         constexpr bool NL = KC > 0 || D::kBig; // no row / column lists in LDS
         ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
         ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
-        ldsd *cd0 = take(p.dense_c_lds ? p.mreg * nz : 0);
+        ldsd *cdn0 = take(p.split_lds ? p.ndp * nz : 0), *sval0 = take(p.split_lds ? p.mreg : 0);
         S.Ls = take(D::kBig ? LM_STAGE(nx, nu) : 0);
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
@@ -2565,6 +2848,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsi *rptr0 = takei(NL ? 0 : p.mreg + 1), *rcol0 = takei(NL ? 0 : p.nnz0), *cptr0 = takei(NL ? 0 : nz + 1);
         ldsi *crow0 = takei(NL ? 0 : p.nnz0);
         ldsi *gptr0 = takei(D::kBig ? 0 : ne + 1), *grow0 = takei(D::kBig ? 0 : p.nng0);
+        ldsi *drow0 = takei(p.split_lds ? p.ndp : 0), *rinfo0 = takei(p.split_lds ? p.mreg : 0), *sptr0 = takei(p.split_lds ? nz + 1 : 0), *srow0 = takei(p.split_lds ? p.ns : 0);
         ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
@@ -2597,9 +2881,15 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
         S.G0 = ListsG{g0.rptr, g0.rcol, g0.cptr, g0.crow, g0.gptr, g0.grow, g0.rval, g0.cval, g0.gval, g0.h};
         S.ccv = cval0;
-        S.Cd = p.dense_c_lds ? cd0 : nullptr;
-        if (p.dense_c_lds)
-            for (int i = lane; i < p.mreg * nz; i += D::kNT) cd0[i] = p.Creg[i];
+        S.Cdn = p.split_lds ? cdn0 : nullptr;
+        S.sval = sval0; S.drow = drow0; S.rinfo = rinfo0; S.sptr = sptr0; S.srow = srow0;
+        if (p.split_lds) {
+            for (int i = lane; i < p.ndp * nz; i += D::kNT) cdn0[i] = p.Cdn[i];
+            for (int i = lane; i < p.mreg; i += D::kNT) { sval0[i] = p.sval[i]; rinfo0[i] = p.rinfo[i]; }
+            for (int i = lane; i < p.ndp; i += D::kNT) drow0[i] = p.drow[i];
+            for (int i = lane; i < nz + 1; i += D::kNT) sptr0[i] = p.sptr[i];
+            for (int i = lane; i < p.ns; i += D::kNT) srow0[i] = p.srow[i];
+        }
         S.cci = cci0;
         S.term_on = 0;
         S.fullfix = 0;
@@ -2834,6 +3124,12 @@ static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &k
         return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv, true>, NWv, Dims<NX, NU, NUB, NWv>::kKC, 0};
 static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
 {
+#ifdef HMPC_DEV_BIG_ONLY
+    // development build (`make dev`): only the streaming form of the generic kernel is instantiated (compiles in a
+    // fraction of the time); never shipped
+    (void)p; (void)nw;
+    return {hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>, hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4, true>, 4, 0, 1};
+#else
     const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr || getenv("HMPC_FORCE_BIG") != nullptr;
     int kf = 0, kb = 0, kt = 0;
     if (!generic && p.nx == 4 && p.nu == 7 && p.nub == 4) {
@@ -2861,6 +3157,7 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
     if (nw == 1) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 1, true>, 1, 0, 0};
     if (nw == 2) return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 2, true>, 2, 0, 0};
     return {hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4>, hmpc_qp_kernel<0, 0, 0, 0, 0, 0, 4, true>, 4, 0, 0};
+#endif
 }
 #undef HMPC_TRY
 #endif
