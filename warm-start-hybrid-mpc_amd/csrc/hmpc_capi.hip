@@ -348,10 +348,20 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
     // generic kernel on the matrix cores (nz >= 16): the dense stage rows go to LDS if they fit beside everything else
     p.split_lds = 0;
+    p.ring = 1;
     if (p.nz >= 16) {
         const bool big = hmpc_lds_bytes(p, 0, 0) > lds_cu || getenv("HMPC_FORCE_BIG");
         p.split_lds = 1;
         if (hmpc_lds_bytes(p, 0, big ? 1 : 0) > lds_cu) p.split_lds = 0;
+    }
+    // streaming form: as many stages per chunk of staged multipliers as LDS has room for
+    for (int r = 4; r >= 1; r--) {
+        p.ring = r;
+        if (hmpc_lds_bytes(p, 0, 1) <= lds_cu) break;
+    }
+    if (const char *e = getenv("HMPC_RING")) {
+        const int r = atoi(e);
+        if (r >= 1 && r <= 4) p.ring = r;
     }
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
@@ -741,8 +751,9 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
                     fprintf(stderr, "hip stamps ph %d %-22s %12.0f cycles %5.1f%%\n", ph, names[k], tr[2 * 64 * 8 + ph * 8 + k], 100 * tr[2 * 64 * 8 + ph * 8 + k] / tot);
         }
         // (the generic kernel's solve stamps its phases as: 6 g = C'e, 7 both sweeps, 8 lam, 9 dz, 10 nu of the fixed binaries)
-        const char *fn[11] = {"F gram+PA", "F assemble col", "F prescribe", "F eliminate", "F writeback+sync", "F Minv", "S g=C'e", "S backward", "S Minv*mu", "S forward", "S lam,dz,dnuf"};
-        for (int k = 0; k < 11; k++)
+        const char *fn[16] = {"F gram+PA", "F assemble col", "F prescribe", "F eliminate", "F writeback+sync", "F count", "S g=C'e", "S backward", "S Minv*mu", "S forward", "S lam,dz,dnuf",
+                              "W prepass", "W first chunk", "W wave 0 recursion", "W chunk barrier", "S count"};
+        for (int k = 0; k < 16; k++)
             if (tr[2 * 64 * 8 + 16 + k] > 0) fprintf(stderr, "hip fine   %-22s %12.0f cycles\n", fn[k], tr[2 * 64 * 8 + 16 + k]);
         (void)hipMemset(h->trace, 0, tr.size() * sizeof(double));
     }

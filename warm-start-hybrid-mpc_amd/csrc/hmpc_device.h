@@ -38,6 +38,7 @@ struct DevProb {
     unsigned *check_flag;                      // diagnostic build (HMPC_CHECK): bits raised by failed in-kernel checks; follows work_counter
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
+    int ring;                                  //   stages per chunk the sweeps of a solve stage in LDS (1 .. 4: what fits)
     // generic kernel, nz >= 16: the stage rows split into DENSE rows (two or more nonzeros: matrix-core contractions and
     // dense products) and SINGLETON rows (one nonzero -- bounds; they only touch the diagonal of C'DC and one component
     // of a product), staged in LDS when they fit beside the rest (split_lds)
@@ -89,7 +90,13 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
     d += nx + nz + 40;                                                    // q mv red
     d += nx;                                                              // x0
-    d += nx * nz + nz * nz + nx * nx;                                     // AB P PT
+    if (big) {                                                            // AB padded, P, PT
+        const size_t nur = (nu + 3) / 4 * 4, nup = (nu + 1 + 3) / 4 * 4, lrows = nz + 1 > nx + nur ? nz + 1 : nx + nur;
+        d += ((nx + 1 + 3) / 4 * 4) * lrows + nz * nz + nx * nx;
+        d += 2 * (size_t)p.ring * lrows * nup + lms;                      // two chunks of `ring` padded stage blocks of multipliers; the stage a factorisation works on
+    } else {
+        d += nx * nz + nz * nz + nx * nx;
+    }
     i += 2 + T * nub + 2 * (size_t)p.ne;                                  // flag fix ei ej
     if (!big) {
         i += (p.ne + 1) + p.nng0;                                         // gptr0 grow0
@@ -108,7 +115,6 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
         d += (size_t)p.ndp * nz + p.mreg;
         i += (size_t)p.ndp + p.mreg + (nz + 1) + p.ns;
     }
-    if (big) d += lms;                                                     // one stage's multipliers staged for the sweeps
     return d * sizeof(double) + i * sizeof(int) + b;
 }
 

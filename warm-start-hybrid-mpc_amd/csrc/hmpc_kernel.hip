@@ -222,7 +222,9 @@ struct Lds {
     ListsL L0;         // stage rows ([F G] and the bounds of the binaries), the same for every stage
     ListsG G0;         // the same lists left in global memory, and the Riccati factor in a global slab:
     double *LmG, *PrG; //   the streaming variant for problems whose factor does not fit in LDS (Dims::kBig)
-    ldsd *Ls;          //   ... and one stage's multipliers staged in LDS for the sweeps of a solve
+    ldsd *Ls;          //   ... two chunks of `ring` stages of multipliers staged in LDS for the sweeps of a solve (padded rows, see kkt_sweeps_wave)
+    ldsd *Lw;          //   ... and the multipliers of the stage a factorisation is working on (packed), flushed to the slab per stage
+    int abst, nup, lrows; // row stride of S.AB; columns / rows of a padded stage block in S.Ls
     // generic kernel, nz >= 16 (DevProb::split_lds; Cdn null otherwise): dense stage rows (ndp x nz), their local rows,
     // per row: singleton column or -(dense index + 1), singleton coefficient; singleton rows by column
     const ldsd *Cdn, *sval;
@@ -257,6 +259,9 @@ struct Dims {
     static DEV int ne(const DevProb &p) { return NX_ > 0 ? (NX_ + NU_) * (NX_ + NU_ + 1) / 2 : p.ne; }
 };
 
+// row stride of [A B] in LDS: the streaming form pads it (zero column nz, zero rows from nx on: the register
+// recursions of its solves read past the ends instead of testing for them); nz everywhere else (a constant there)
+#define AB_STRIDE (D::kBig ? S.abst : nz)
 template <class D> DEV decltype(auto) stage_lists(const Lds &S)
 {
     if constexpr (D::kBig) return (S.G0);
@@ -779,7 +784,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
         for (int e = lane; e < nx * nz; e += D::kNT) {
             const int i = e / nz, j = e - i * nz;
             double a = 0;
-            for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * S.AB[l * nz + j];
+            for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * S.AB[l * AB_STRIDE + j];
             S.PA[e] = a;
         }
         __syncthreads();
@@ -787,7 +792,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
         for (int e = lane; e < ne; e += D::kNT) {
             const int i = S.ei[e], j = S.ej[e];
             double a = S.Mm[i * nz + j];
-            for (int l = 0; l < nx; l++) a += S.AB[l * nz + i] * S.PA[l * nz + j];
+            for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + i] * S.PA[l * nz + j];
             S.Mm[i * nz + j] = a;
             S.Mm[j * nz + i] = a;
         }
@@ -797,7 +802,7 @@ template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAM
         // the stage's multipliers are collected in LDS (the streaming form flushes the block to its slab once per
         // stage, coalesced, instead of one scattered global store per pivot and row)
         ldsd *Lw;
-        if constexpr (D::kBig) Lw = S.Ls;
+        if constexpr (D::kBig) Lw = S.Lw;
         else Lw = S.Lm + t * lms;
         if (!DBG_SKIP(1))
             for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
@@ -906,7 +911,7 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
         mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
         acc = mfma_tile(wl, nx,
                         [&](int r, int k) { const int i = ti * 16 + r; const double v = Pn[(i < nx ? i : nx - 1) * pns + k]; return i < nx ? v : 0.0; },
-                        [&](int k, int c) { const int j = tj * 16 + c; const double v = S.AB[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
+                        [&](int k, int c) { const int j = tj * 16 + c; const double v = S.AB[k * AB_STRIDE + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         const int j = tj * 16 + (wl & 15);
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -933,7 +938,7 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
                             [&](int k, int c) { const int j = tj * 16 + c; const double v = p.Ct[(size_t)k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         }
         acc = mfma_tile(wl, nx,
-                        [&](int r, int k) { const int i = ti * 16 + r; const double v = S.AB[k * nz + (i < nz ? i : nz - 1)]; return i < nz ? v : 0.0; },
+                        [&](int r, int k) { const int i = ti * 16 + r; const double v = S.AB[k * AB_STRIDE + (i < nz ? i : nz - 1)]; return i < nz ? v : 0.0; },
                         [&](int k, int c) { const int j = tj * 16 + c; const double v = S.PA[k * nz + (j < nz ? j : nz - 1)]; return j < nz ? v : 0.0; }, acc);
         const int j = tj * 16 + (wl & 15);
 #pragma unroll
@@ -1005,6 +1010,9 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     const int wl = lane & 63, wave = __builtin_amdgcn_readfirstlane(lane >> 6), r0 = wl >> 4, c0 = wl & 15; // (wave: uniform, so that everything per tile is scalar)
     const int tn = (nz + 15) >> 4, tx = (nx + 15) >> 4, ntile = tn * (tn + 1) / 2;
+#ifdef HMPC_STAMPS
+    facc[5] += 1; // (count of factorisations)
+#endif
     ldsd *Mf = S.Mm;           // the matrix as the other lanes see it: dense nz x nz, both triangles
     ldsd *dump = S.red + 39;   // where the entries of a tile that overhang the matrix are written
     // this lane's entries: tile qq -> rows row0[qq] + 4 r, column colq[qq]
@@ -1066,7 +1074,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
             mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
             acc = mfma_tile_batched<5>(wl, nx,
                                        [&](int, int k) { const double v = Pn[ic * pns + k]; return i < nx ? v : 0.0; },
-                                       [&](int k, int) { const double v = S.AB[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                                       [&](int k, int) { const double v = S.AB[k * AB_STRIDE + jc]; return j < nz ? v : 0.0; }, acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int ii = ti * 16 + r0 + 4 * r;
@@ -1102,7 +1110,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                                                [&](int k, int) { const double v = p.Ct[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
                 }
                 acc = mfma_tile_batched<5>(wl, nx,
-                                           [&](int, int k) { const double v = S.AB[k * nz + ic]; return i < nz ? v : 0.0; },
+                                           [&](int, int k) { const double v = S.AB[k * AB_STRIDE + ic]; return i < nz ? v : 0.0; },
                                            [&](int k, int) { const double v = S.PA[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -1129,7 +1137,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         FSTAMP(0);
         // (3) fixed binaries: mb = sum of the columns of the binaries fixed to one, then identity rows / columns
         ldsd *Lw;
-        if constexpr (D::kBig) Lw = S.Ls;
+        if constexpr (D::kBig) Lw = S.Lw;
         else Lw = S.Lm + t * lms;
         for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
         if (nfixed) {
@@ -1467,8 +1475,9 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
 // works on the current one.  Skipped pivots (fixed binaries) have zero multipliers: their steps are no-ops.
 // On entry: S.g = stage gradients, S.pv[T] set.  On exit: dw (x and u), S.pv (p_t) as the barrier form leaves them.
 template <class D>
-DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, const ldsd *csrc, double cs, bool useb, ldsd *dw)
+DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, const ldsd *csrc, double cs, bool useb, ldsd *dw FSTAMP_ARGS)
 {
+    FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     const bool w0 = lane < WAVE;
@@ -1482,117 +1491,295 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
         }
         S.pv[o] = a;
     }
-    // staging of one stage's multipliers (streaming form): every thread but wave 0's carries part of the next block
-    constexpr int STG = 8; // doubles per fetching thread: covers lms <= 8 * (kNT - 64) (checked by the caller)
-    double stage_reg[STG];
-    const int fetchers = D::kNT > WAVE ? D::kNT - WAVE : D::kNT, fid = D::kNT > WAVE ? lane - WAVE : lane;
-    auto fetch = [&](int t) {
-        if constexpr (D::kBig) {
-            if (fid >= 0) {
-                const double *src = S.LmG + (size_t)t * lms;
-#pragma unroll
-                for (int q = 0; q < STG; q++) {
-                    const int e = fid + q * fetchers;
-                    stage_reg[q] = e < lms ? src[e] : 0.0;
-                }
-            }
-        }
-    };
-    auto commit = [&]() {
-        if constexpr (D::kBig) {
-            if (fid >= 0) {
-#pragma unroll
-                for (int q = 0; q < STG; q++) {
-                    const int e = fid + q * fetchers;
-                    if (e < lms) S.Ls[e] = stage_reg[q];
-                }
-            }
-        }
-    };
-    auto block = [&](int t) -> const ldsd * {
-        if constexpr (D::kBig) return S.Ls;
-        else return S.Lm + t * lms;
-    };
     double pvr = 0.0; // lane i < nx of wave 0: p_{t+1}[i]
-    if (w0 && lane < nx) pvr = S.pv[T * nx + lane];
-    fetch(T - 1);
-    __syncthreads();
-    commit();
-    __syncthreads();
-    // ---- backward sweep
-    for (int t = T - 1; t >= 0; t--) {
-        if (D::kNT > WAVE ? !w0 : false) {
-            if (t > 0) fetch(t - 1);
-        } else if (w0) {
-            const ldsd *Lm = block(t);
+    double xr = 0.0;  //                        x_t[i] (forward sweep)
+    // The recursions take their coefficients (a column of [A B], a row / column of the multipliers) from LDS in blocks of
+    // eight: all loads of a block are in flight before its first product, indices past the end are clamped and their
+    // coefficients zeroed -- a load inside the step that uses it puts one LDS round trip on every step of the chain
+    // (measured: 5.7 k cycles per stage and sweep on configs[4], against 1.5 k in this form).
+    constexpr int BK = 8;
+    // one stage of the backward sweep (wave 0; Lm: the stage's multipliers in LDS)
+    auto backward = [&](int t, const ldsd *Lm) {
+        const ldsi *fx = S.fix + t * nub;
+        const int j = lane;
+        const double qv = lane < nx ? pvr + S.pv[t * nx + lane] : 0.0;
+        const int jc = j < nz ? j : 0;
+        double v = j < nz ? S.g[t * nz + jc] : 0.0, v1 = 0.0;
+        for (int l0 = 0; l0 < nx; l0 += BK) {
+            double c[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int l = l0 + i;
+                const double x = S.AB[(l < nx ? l : nx - 1) * AB_STRIDE + jc];
+                c[i] = (l < nx && j < nz) ? x : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int l = l0 + i;
+                const double q = bcast(qv, l < WAVE ? l : WAVE - 1);
+                if (i & 1) v1 += c[i] * q;
+                else v += c[i] * q;
+            }
+        }
+        v += v1;
+        if (j >= nx + nuc && j < nz) {
+            const int f = fx[j - nx - nuc];
+            if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
+        }
+        // forward substitution: the factorisation's row operations applied to the vector
+        const int rowoff = j < nx ? LM_X(nx, nu, j, 0) : j < nz ? LM_U(nx, nu, j - nx, 0) : 0;
+        const int rowlen = j < nx ? nu : j < nz ? j - nx : 0;
+        for (int j0 = 0; j0 < nu; j0 += BK) {
+            double c[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int jj = j0 + i;
+                const double x = Lm[rowoff + (jj < rowlen ? jj : 0)];
+                c[i] = jj < rowlen ? x : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int src = nx + j0 + i;
+                v -= c[i] * bcast(v, src < WAVE ? src : WAVE - 1);
+            }
+        }
+        if (j >= nx && j < nz) dw[t * nz + j] = v; // y = L_u^{-1} m_u, parked in the input slots
+        pvr = v;
+        if (j < nx) S.pv[t * nx + j] = v;
+    };
+    // one stage of the forward sweep
+    auto forward = [&](int t, const ldsd *Lm) {
+        const int j = lane;
+        // c = L_x' x + dinv .* y ; x_next = c_dyn + A x (+ B u below)
+        double cur = j < nu ? S.dinv[t * nu + (j < nu ? j : 0)] * dw[t * nz + nx + (j < nu ? j : 0)] : 0.0;
+        double xn = (csrc && j < nx) ? cs * csrc[t * nx + j] : 0.0;
+        const int ju = j < nu ? j : 0, jx = j < nx ? j : 0;
+        for (int l0 = 0; l0 < nx; l0 += BK) {
+            double cl[BK], ca[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int l = l0 + i, lc = l < nx ? l : nx - 1;
+                const double x = Lm[LM_X(nx, nu, lc, ju)], y = S.AB[jx * AB_STRIDE + lc];
+                cl[i] = (l < nx && j < nu) ? x : 0.0;
+                ca[i] = (l < nx && j < nx) ? y : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int l = l0 + i;
+                const double xl = bcast(xr, l < WAVE ? l : WAVE - 1);
+                cur += cl[i] * xl;
+                xn += ca[i] * xl;
+            }
+        }
+        // back substitution with L_u' ; u_jj = -(value of lane jj once its turn has come)
+        for (int j0 = (nu - 1) / BK * BK; j0 >= 0; j0 -= BK) {
+            double cl[BK], ca[BK];
+#pragma unroll
+            for (int i = 0; i < BK; i++) {
+                const int jj = j0 + i, jjc = jj < nu ? jj : nu - 1;
+                const double x = Lm[LM_U(nx, nu, (j < jjc ? jjc : 1), (j < jjc ? j : 0))], y = S.AB[jx * AB_STRIDE + nx + jjc];
+                cl[i] = (jj < nu && j < jj) ? x : 0.0;
+                ca[i] = (jj < nu && j < nx) ? y : 0.0;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = BK - 1; i >= 0; i--) {
+                const int jj = j0 + i;
+                const double uj = bcast(cur, jj < WAVE ? jj : WAVE - 1);
+                cur -= cl[i] * uj;
+                xn -= ca[i] * uj;
+            }
+        }
+        if (j < nx) dw[t * nz + j] = xr;
+        if (j < nu) dw[t * nz + nx + j] = -cur;
+        xr = xn;
+    };
+    if constexpr (!D::kBig) {
+        __syncthreads();
+        if (w0) {
+            if (lane < nx) pvr = S.pv[T * nx + lane];
+            for (int t = T - 1; t >= 0; t--) backward(t, S.Lm + t * lms);
+        }
+        __syncthreads();
+        if (w0) {
+            xr = (lane < nx && usex0) ? S.x0[lane] : 0.0;
+            for (int t = 0; t < T; t++) forward(t, S.Lm + t * lms);
+            if (lane < nx) dw[T * nz + lane] = xr;
+        }
+        __syncthreads();
+    } else {
+        // Streaming form: the multipliers live in the global slab.  The other waves (one wave per node: the wave itself)
+        // bring them to LDS in CHUNKS of `ring` stages, two chunk buffers: while wave 0 runs the recursion over chunk g
+        // the loads of chunk g + 1 are in flight, one workgroup barrier per chunk.  Chunks 0 .. nch-1 walk the horizon
+        // backwards, chunks nch .. 2 nch - 1 forwards.
+        // In LDS a stage block is PADDED: row i (component i of the stage vector) holds its multipliers in nup columns,
+        // zero beyond its entries, and zero rows follow the last component; [A B] carries a zero column and zero rows
+        // likewise.  Wave 0 -- the only wave at work, its instruction count IS the time of a solve -- then runs fixed
+        // four-wide steps with no bound tests, clamps or selects: a term past the end multiplies a zero (measured on
+        // configs[4]: 7 k cycles per stage and sweep with tested / clamped loads, [see DESIGN 4.2] in this form).
+        constexpr int RMAX = 4, STG = 8; // stages per chunk; doubles per fetching thread and stage: lms <= 8 * fetchers (checked by the caller)
+        const int R = p.ring, nch = (T + R - 1) / R;
+        const int fetchers = D::kNT > WAVE ? D::kNT - WAVE : D::kNT, fid = D::kNT > WAVE ? lane - WAVE : lane;
+        const bool helper = fid >= 0;
+        const int nup = S.nup, slot = S.lrows * nup, abst = S.abst;
+        const int nxr = (nx + 3) / 4 * 4, nur = (nu + 3) / 4 * 4;
+        double stage_reg[RMAX][STG];
+        int dsto[STG]; // packed entry e = fid + q fetchers of a stage block -> its place in the padded block
+#pragma unroll
+        for (int q = 0; q < STG; q++) {
+            int e = fid + q * fetchers;
+            e = e < lms && e >= 0 ? e : lms - 1;
+            int row, col;
+            if (e < nx * nu) {
+                row = e / nu;
+                col = e - row * nu;
+            } else {
+                const int k = e - nx * nu; // L_u packed by rows: row i holds its i entries
+                int i = (int)((1.0f + sqrtf(1.0f + 8.0f * (float)k)) * 0.5f);
+                while (i * (i - 1) / 2 > k) i--;
+                while ((i + 1) * i / 2 <= k) i++;
+                row = nx + i;
+                col = k - i * (i - 1) / 2;
+            }
+            dsto[q] = row * nup + col;
+        }
+        auto stage_of = [&](int g, int sidx) { // stage of slot sidx of chunk g, -1: none
+            const int t = g < nch ? T - 1 - g * R - sidx : (g - nch) * R + sidx;
+            return (t >= 0 && t < T) ? t : -1;
+        };
+        auto fetch = [&](int g) {
+#pragma unroll
+            for (int sidx = 0; sidx < RMAX; sidx++) {
+                const int t = sidx < R ? stage_of(g, sidx) : -1;
+                if (t >= 0) {
+                    const double *src = S.LmG + (size_t)t * lms;
+#pragma unroll
+                    for (int q = 0; q < STG; q++) {
+                        // (clamped, not predicated: a load under a lane predicate sits in a branch of its own and waits for
+                        // itself -- one slab latency per load instead of one per chunk)
+                        const int e = fid + q * fetchers;
+                        if (q * fetchers < lms) stage_reg[sidx][q] = src[e < lms ? e : lms - 1];
+                    }
+                }
+            }
+        };
+        auto commit = [&](int g) {
+            ldsd *dst = S.Ls + (g & 1) * R * slot;
+#pragma unroll
+            for (int sidx = 0; sidx < RMAX; sidx++) {
+                const int t = sidx < R ? stage_of(g, sidx) : -1;
+                if (t >= 0) {
+#pragma unroll
+                    for (int q = 0; q < STG; q++) {
+                        const int e = fid + q * fetchers;
+                        if (e < lms) dst[sidx * slot + dsto[q]] = stage_reg[sidx][q];
+                    }
+                }
+            }
+        };
+        // one stage of the backward sweep on a padded block
+        auto backward_p = [&](int t, const ldsd *Lp) {
             const ldsi *fx = S.fix + t * nub;
-            const int j = lane;
+            const int j = lane, jc = j < nz ? j : nz; // (column nz of [A B] and row nz of the block are zero)
             const double qv = lane < nx ? pvr + S.pv[t * nx + lane] : 0.0;
-            const int jc = j < nz ? j : 0;
-            double v = j < nz ? S.g[t * nz + jc] : 0.0;
-            for (int l = 0; l < nx; l++) v += (j < nz ? S.AB[l * nz + jc] : 0.0) * bcast(qv, l);
+            double v0 = j < nz ? S.g[t * nz + (j < nz ? j : 0)] : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            const ldsd *ab = S.AB + jc;
+            for (int l = 0; l < nxr; l += 4) { // (rows nx .. nxr-1 of [A B] are zero rows)
+                const double c0 = ab[0], c1 = ab[abst], c2 = ab[2 * abst], c3 = ab[3 * abst];
+                ab += 4 * abst;
+                v0 += c0 * bcast(qv, l);
+                v1 += c1 * bcast(qv, l + 1);
+                v2 += c2 * bcast(qv, l + 2);
+                v3 += c3 * bcast(qv, l + 3);
+            }
+            double v = (v0 + v1) + (v2 + v3);
             if (j >= nx + nuc && j < nz) {
                 const int f = fx[j - nx - nuc];
                 if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
             }
             // forward substitution: the factorisation's row operations applied to the vector
-            const int rowoff = j < nx ? LM_X(nx, nu, j, 0) : j < nz ? LM_U(nx, nu, j - nx, 0) : 0;
-            const int rowlen = j < nx ? nu : j < nz ? j - nx : 0;
-            for (int jj = 0; jj < nu; jj++) {
-                const double yj = bcast(v, nx + jj);
-                if (jj < rowlen) v -= Lm[rowoff + jj] * yj;
+            const ldsd *lr = Lp + jc * nup;
+            for (int jj = 0; jj < nur; jj += 4) {
+                const double c0 = lr[jj], c1 = lr[jj + 1], c2 = lr[jj + 2], c3 = lr[jj + 3];
+                const int s0 = nx + jj;
+                v -= c0 * bcast(v, s0 < WAVE ? s0 : WAVE - 1);
+                v -= c1 * bcast(v, s0 + 1 < WAVE ? s0 + 1 : WAVE - 1);
+                v -= c2 * bcast(v, s0 + 2 < WAVE ? s0 + 2 : WAVE - 1);
+                v -= c3 * bcast(v, s0 + 3 < WAVE ? s0 + 3 : WAVE - 1);
             }
             if (j >= nx && j < nz) dw[t * nz + j] = v; // y = L_u^{-1} m_u, parked in the input slots
             pvr = v;
             if (j < nx) S.pv[t * nx + j] = v;
-        }
-        if constexpr (D::kBig) {
-            if (D::kNT == WAVE && t > 0) fetch(t - 1); // one wave only: it fetches for itself
-            __syncthreads();
-            if (t > 0) commit();
-            __syncthreads();
-        }
-    }
-    if constexpr (!D::kBig) __syncthreads();
-    // ---- forward sweep
-    fetch(0);
-    __syncthreads();
-    commit();
-    __syncthreads();
-    double xr = (w0 && lane < nx && usex0) ? S.x0[lane] : 0.0;
-    for (int t = 0; t < T; t++) {
-        if (D::kNT > WAVE ? !w0 : false) {
-            if (t + 1 < T) fetch(t + 1);
-        } else if (w0) {
-            const ldsd *Lm = block(t);
-            const int j = lane;
+        };
+        // one stage of the forward sweep on a padded block
+        auto forward_p = [&](int t, const ldsd *Lp) {
+            const int j = lane, jr = j < nx ? j : nx, ju = j < nu ? j : nu; // (row nx of [A B] and column nu of the block are zero)
             // c = L_x' x + dinv .* y ; x_next = c_dyn + A x (+ B u below)
-            double cur = j < nu ? S.dinv[t * nu + j] * dw[t * nz + nx + j] : 0.0;
-            double xn = (csrc && j < nx) ? cs * csrc[t * nx + j] : 0.0;
-            for (int l = 0; l < nx; l++) {
-                const double xl = bcast(xr, l);
-                if (j < nu) cur += Lm[LM_X(nx, nu, l, j)] * xl;
-                if (j < nx) xn += S.AB[j * nz + l] * xl;
+            double cur = j < nu ? S.dinv[t * nu + (j < nu ? j : 0)] * dw[t * nz + nx + (j < nu ? j : 0)] : 0.0;
+            double xn = (csrc && j < nx) ? cs * csrc[t * nx + (j < nx ? j : 0)] : 0.0;
+            const ldsd *lc = Lp + ju, *ar = S.AB + jr * abst;
+            for (int l = 0; l < nxr; l += 4) { // (lanes nx .. of x are zero: what a term past nx multiplies does not matter)
+                const double a0 = ar[l], a1 = ar[l + 1], a2 = ar[l + 2], a3 = ar[l + 3];
+                const double c0 = lc[0], c1 = lc[nup], c2 = lc[2 * nup], c3 = lc[3 * nup];
+                lc += 4 * nup;
+                const double x0 = bcast(xr, l), x1 = bcast(xr, l + 1), x2 = bcast(xr, l + 2), x3 = bcast(xr, l + 3);
+                cur += c0 * x0; xn += a0 * x0;
+                cur += c1 * x1; xn += a1 * x1;
+                cur += c2 * x2; xn += a2 * x2;
+                cur += c3 * x3; xn += a3 * x3;
             }
             // back substitution with L_u' ; u_jj = -(value of lane jj once its turn has come)
-            for (int jj = nu - 1; jj >= 0; jj--) {
-                const double uj = bcast(cur, jj);
-                if (j < jj) cur -= Lm[LM_U(nx, nu, jj, j)] * uj;
-                if (j < nx) xn -= S.AB[j * nz + nx + jj] * uj;
+            const ldsd *lu = Lp + (nx + nur) * nup + ju, *au = ar + nx + nur;
+            for (int jj = nur - 4; jj >= 0; jj -= 4) {
+                lu -= 4 * nup;
+                au -= 4;
+                const double c3 = lu[3 * nup], c2 = lu[2 * nup], c1 = lu[nup], c0 = lu[0];
+                const double a3 = au[3], a2 = au[2], a1 = au[1], a0 = au[0];
+                double uj = bcast(cur, jj + 3);
+                cur -= c3 * uj; xn -= a3 * uj;
+                uj = bcast(cur, jj + 2);
+                cur -= c2 * uj; xn -= a2 * uj;
+                uj = bcast(cur, jj + 1);
+                cur -= c1 * uj; xn -= a1 * uj;
+                uj = bcast(cur, jj);
+                cur -= c0 * uj; xn -= a0 * uj;
             }
             if (j < nx) dw[t * nz + j] = xr;
             if (j < nu) dw[t * nz + nx + j] = -cur;
             xr = xn;
-        }
-        if constexpr (D::kBig) {
-            if (D::kNT == WAVE && t + 1 < T) fetch(t + 1);
+        };
+        FSTAMP(11);
+#ifdef HMPC_STAMPS
+        facc[15] += 1; // (count of solves)
+#endif
+        if (helper) { fetch(0); commit(0); }
+        __syncthreads();
+        FSTAMP(12);
+        if (w0 && lane < nx) pvr = S.pv[T * nx + lane];
+        for (int g = 0; g < 2 * nch; g++) {
+            const bool more = g + 1 < 2 * nch;
+            if (helper && more) fetch(g + 1);
+            if (w0) {
+                if (g == nch) xr = (lane < nx && usex0) ? S.x0[lane] : 0.0;
+                const ldsd *buf = S.Ls + (g & 1) * R * slot;
+                for (int sidx = 0; sidx < R; sidx++) {
+                    const int t = stage_of(g, sidx);
+                    if (t < 0) break;
+                    if (g < nch) backward_p(t, buf + sidx * slot);
+                    else forward_p(t, buf + sidx * slot);
+                }
+            }
+            FSTAMP(13);
+            if (helper && more) commit(g + 1);
             __syncthreads();
-            if (t + 1 < T) commit();
-            __syncthreads();
+            FSTAMP(14);
         }
+        if (w0 && lane < nx) dw[T * nz + lane] = xr;
+        __syncthreads();
     }
-    if (w0 && lane < nx) dw[T * nz + lane] = xr;
-    __syncthreads();
 }
 
 template <class D, int RS, class RM>
@@ -1611,7 +1798,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     __syncthreads();
     const bool wave_sweeps = nz <= WAVE && (!D::kBig || lms <= 8 * (D::kNT > WAVE ? D::kNT - WAVE : D::kNT));
     FSTAMP(6);
-    if (wave_sweeps) kkt_sweeps_wave<D>(p, S, lane, usex0, csrc, cs, useb, dw);
+    if (wave_sweeps) kkt_sweeps_wave<D>(p, S, lane, usex0, csrc, cs, useb, dw FSTAMP_PASS);
     FSTAMP(7);
     // backward sweep (barrier form: stage vectors wider than a wave)
     for (int t = wave_sweeps ? -1 : T - 1; t >= 0; t--) {
@@ -1630,7 +1817,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         }
         for (int j = lane; j < nz; j += D::kNT) {
             double a = S.g[t * nz + j];
-            for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * qv[l];
+            for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + j] * qv[l];
             if (j >= nx + nuc) {
                 const int f = fx[j - nx - nuc];
                 if (f >= 0) a = (useb && f == 1) ? -1.0 : 0.0;
@@ -1684,7 +1871,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         __syncthreads();
         for (int i = lane; i < nx; i += D::kNT) {
             double a = csrc ? cs * csrc[t * nx + i] : 0.0;
-            for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * dw[t * nz + l];
+            for (int l = 0; l < nz; l++) a += S.AB[i * AB_STRIDE + l] * dw[t * nz + l];
             dw[(t + 1) * nz + i] = a;
         }
         __syncthreads();
@@ -1717,7 +1904,7 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
             a = own_g ? gs * gsrc[t * nz + c] : 0.0;
             for (int j = 0; j < nz; j++) a -= S.P[c * nz + j] * dw[t * nz + j];
             a -= ccol_dot<D>(p, S, t, c, S.e);
-            for (int l = 0; l < nx; l++) a += S.AB[l * nz + c] * dlam[(t + 1) * nx + l];
+            for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + c] * dlam[(t + 1) * nx + l];
         }
         dnuf[o] = a;
     }
@@ -2147,7 +2334,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 a = S.lam[T * nx + j];
             } else {
                 if (j < nx) a += S.lam[t * nx + j];
-                for (int l = 0; l < nx; l++) a -= S.AB[l * nz + j] * S.lam[(t + 1) * nx + l];
+                for (int l = 0; l < nx; l++) a -= S.AB[l * AB_STRIDE + j] * S.lam[(t + 1) * nx + l];
                 if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a += S.nuf[t * nub + (j - nx - nuc)];
                 a += ccol_dot<D>(p, S, t, j, S.e);
             }
@@ -2167,7 +2354,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         for (int o = lane; o < T * nx; o += D::kNT) {
             const int t = o / nx, i = o - t * nx;
             double a = S.w[(t + 1) * nz + i];
-            for (int l = 0; l < nz; l++) a -= S.AB[i * nz + l] * S.w[t * nz + l];
+            for (int l = 0; l < nz; l++) a -= S.AB[i * AB_STRIDE + l] * S.w[t * nz + l];
             S.rdyn[o] = a;
             rcinf = fmax(rcinf, fabs(a));
         }
@@ -2599,7 +2786,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         a -= S.lam2[T * nx + j];
                     } else {
                         if (j < nx) a -= S.lam2[t * nx + j];
-                        for (int l = 0; l < nx; l++) a += S.AB[l * nz + j] * S.lam2[(t + 1) * nx + l];
+                        for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + j] * S.lam2[(t + 1) * nx + l];
                         a -= ccol_dot<D>(p, S, t, j, S.e);
                         if (j >= nx + nuc && S.fix[t * nub + (j - nx - nuc)] >= 0) a = 0.0;
                         if (t == 0 && j < nx) a = 0.0;
@@ -2609,7 +2796,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 for (int o = lane; o < T * nx; o += D::kNT) {
                     const int t = o / nx, i = o - t * nx;
                     double a = -lin * S.rdyn[o] - S.w2[(t + 1) * nz + i];
-                    for (int l = 0; l < nz; l++) a += S.AB[i * nz + l] * S.w2[t * nz + l];
+                    for (int l = 0; l < nz; l++) a += S.AB[i * AB_STRIDE + l] * S.w2[t * nz + l];
                     S.edyn[o] = a;
                 }
                 __syncthreads();
@@ -2831,7 +3018,18 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.Mm = S.w2; S.PA = S.Mm + nz * nz;
         S.q = take(nx); S.mv = take(nz); S.red = take(40);
         S.x0 = take(nx);
-        S.AB = take(nx * nz); S.P = take(nz * nz); S.PT = take(nx * nx);
+        // streaming form: [A B] padded (zero column nz, zero rows nx ..), stage blocks of multipliers padded to
+        // lrows x nup (zero beyond a row's entries) -- must mirror hmpc_pad_dims() in hmpc_device.h
+        S.abst = nz; S.nup = 0; S.lrows = 0;
+        int abrows = nx;
+        if constexpr (D::kBig) {
+            const int nur = (nu + 3) / 4 * 4;
+            S.nup = (nu + 1 + 3) / 4 * 4;
+            S.lrows = nz + 1 > nx + nur ? nz + 1 : nx + nur;
+            S.abst = S.lrows;
+            abrows = (nx + 1 + 3) / 4 * 4;
+        }
+        S.AB = take(abrows * S.abst); S.P = take(nz * nz); S.PT = take(nx * nx);
         // lists of the regular stage: the generic kernel stages rows, columns and Gram lists; the
         // compile-time shapes padded columns and Gram lists (their rows live in registers)
         constexpr int KC = D::kKC;
@@ -2839,7 +3037,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
         ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
         ldsd *cdn0 = take(p.split_lds ? p.ndp * nz : 0), *sval0 = take(p.split_lds ? p.mreg : 0);
-        S.Ls = take(D::kBig ? LM_STAGE(nx, nu) : 0);
+        S.Ls = take(D::kBig ? 2 * p.ring * S.lrows * S.nup : 0); // two chunk buffers of `ring` padded stage blocks (kkt_sweeps_wave)
+        S.Lw = take(D::kBig ? LM_STAGE(nx, nu) : 0);
+        if constexpr (D::kBig)
+            for (int i = lane; i < 2 * p.ring * S.lrows * S.nup; i += D::kNT) S.Ls[i] = 0.0; // (the padding stays zero: only entries are ever written)
         ldsi *qi = (ldsi *)q;
         auto takei = [&](int cnt) { ldsi *r = qi; qi += cnt; return r; };
         S.flag = takei(2);
@@ -2852,9 +3053,12 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
+        if constexpr (D::kBig)
+            for (int i = lane; i < abrows * S.abst; i += D::kNT) S.AB[i] = 0.0;
+        __syncthreads();
         for (int i = lane; i < nx * nz; i += D::kNT) {
             const int l = i / nz, j = i - l * nz;
-            S.AB[i] = j < nx ? p.A[l * nx + j] : p.B[l * nu + (j - nx)];
+            S.AB[l * AB_STRIDE + j] = j < nx ? p.A[l * nx + j] : p.B[l * nu + (j - nx)];
         }
         for (int i = lane; i < nz * nz; i += D::kNT) S.P[i] = p.P[i];
         for (int i = lane; i < nx * nx; i += D::kNT) S.PT[i] = p.PT[i];
