@@ -1048,6 +1048,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         const int i = e / nx, j = e - i * nx;
         if (i >= j) fac_pr<D>(S)[T * nxs + sym(i, j)] = S.PT[e];
     }
+    if (lane == 0) S.flag[0] = 0;
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *Pn = t == T - 1 ? S.PT : Mf; // P_{t+1}: the terminal Hessian, or the block the previous stage left
@@ -1073,8 +1074,8 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
             const int i = ti * 16 + c0, ic = i < nx ? i : nx - 1, j = tj * 16 + c0, jc = j < nz ? j : nz - 1;
             mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
             acc = mfma_tile_batched<5>(wl, nx,
-                                       [&](int, int k) { const double v = Pn[ic * pns + k]; return i < nx ? v : 0.0; },
-                                       [&](int k, int) { const double v = S.AB[k * AB_STRIDE + jc]; return j < nz ? v : 0.0; }, acc);
+                                       [&](int, int k) { return Pn[ic * pns + k]; },
+                                       [&](int k, int) { return S.AB[k * AB_STRIDE + jc]; }, acc);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int ii = ti * 16 + r0 + 4 * r;
@@ -1082,7 +1083,9 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
             }
         }
         lds_barrier();
-        // (2) the tiles of M, in registers
+        // (2) the tiles of M, in registers.  Rows / columns of a tile past nz are read from clamped indices and NOT zeroed:
+        // an entry of the product only sees its own row of the first and its own column of the second operand, and the
+        // entries past nz are never used.
         double m[MQ][4];
         const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
         const bool term = S.term_on && t == T - 1;
@@ -1097,8 +1100,8 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                 mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
                 if (S.Cdn) // the dense rows; the singleton rows only reach the diagonal (sdg)
                     acc = mfma_tile_batched<4>(wl, p.ndp,
-                                               [&](int, int k) { const double v = S.Cdn[k * nz + ic] * Dt[S.drow[k]]; return i < nz ? v : 0.0; },
-                                               [&](int k, int) { const double v = S.Cdn[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                                               [&](int, int k) { return S.Cdn[k * nz + ic] * Dt[S.drow[k]]; },
+                                               [&](int k, int) { return S.Cdn[k * nz + jc]; }, acc);
                 else
                     acc = mfma_tile_batched<5>(wl, p.mreg,
                                                [&](int, int k) { const double v = p.Creg[(size_t)k * nz + ic] * Dt[k]; return i < nz ? v : 0.0; },
@@ -1110,8 +1113,8 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                                                [&](int k, int) { const double v = p.Ct[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
                 }
                 acc = mfma_tile_batched<5>(wl, nx,
-                                           [&](int, int k) { const double v = S.AB[k * AB_STRIDE + ic]; return i < nz ? v : 0.0; },
-                                           [&](int k, int) { const double v = S.PA[k * nz + jc]; return j < nz ? v : 0.0; }, acc);
+                                           [&](int, int k) { return S.AB[k * AB_STRIDE + ic]; },
+                                           [&](int k, int) { return S.PA[k * nz + jc]; }, acc);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = row0[qq] + 4 * r, rc = row < nz ? row : nz - 1;
@@ -1140,6 +1143,90 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         if constexpr (D::kBig) Lw = S.Lw;
         else Lw = S.Lm + t * lms;
         for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
+        constexpr int NUM = 16; // inputs the panel form holds per lane
+        if (nu <= NUM) {
+            // PANEL FORM.  The elimination only ever reads the input columns of M: the panel M[:, nx .. nz) (nz x nu) is
+            // factorised by wave 0 ALONE, lane i holding row i in registers, the pivot row broadcast with v_readlane -- no
+            // barrier between pivots, a third of the instructions of the tile form below --, and the state block follows in
+            // one step on the matrix cores:  P_t = M_xx - L_x A_x'  (A_x: the panel's state rows as they stood when their
+            // column was the pivot; same operations as pivot-by-pivot, each entry's subtractions in the same order).
+            lds_barrier(); // M as published, Lw zeroed
+            if (lane < WAVE) {
+                const int i = lane, ic = i < nz ? i : 0, b0 = nx + nuc;
+                unsigned fixmask = 0; // bit k: input k is a binary the node fixes (wave uniform)
+                for (int b = 0; b < nub; b++)
+                    if (fx[b] >= 0) fixmask |= 1u << (nuc + b);
+                fixmask = __builtin_amdgcn_readfirstlane(fixmask);
+                if (i < nz) {
+                    double g = 0;
+                    if (nfixed)
+                        for (int b = 0; b < nub; b++)
+                            if (fx[b] == 1) g += Mf[i * nz + b0 + b];
+                    S.g[t * nz + i] = g;
+                }
+                const bool rowfixed = i >= nx && i < nz && ((fixmask >> (i - nx)) & 1u);
+                double a[NUM];
+#pragma unroll
+                for (int k = 0; k < NUM; k++) {
+                    const double x = Mf[ic * nz + nx + (k < nu ? k : 0)];
+                    const bool pres = rowfixed || ((fixmask >> k) & 1u); // prescribed component: identity row / column
+                    a[k] = (k < nu && i < nz) ? (pres ? (i == nx + k ? 1.0 : 0.0) : x) : 0.0;
+                }
+                // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
+                // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
+                int nuo = nu;
+#pragma unroll
+                for (int j = 0; j < NUM; j++) {
+                    asm volatile("" : "+s"(nuo), "+s"(fixmask));
+                    if (j < nuo) {
+                        if (i < nz) Mf[i * nz + nx + j] = a[j]; // the column as it stands: second operand of the state block's product
+                        if ((fixmask >> j) & 1u) { // decoupled unit pivot: the solves skip it as well
+                            if (lane == 0) S.dinv[t * nu + j] = 1.0;
+                        } else {
+                            const double d = bcast(a[j], nx + j);
+                            if (!(d > 0.0)) bad = 1;
+                            double rinv = __builtin_amdgcn_rcp(d);
+                            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
+                            const bool trailing = i < nx || (i > nx + j && i < nz);
+                            const double mval = a[j] * rinv, meff = trailing ? mval : 0.0;
+#pragma unroll
+                            for (int k = j + 1; k < NUM; k++) a[k] -= meff * bcast(a[k], nx + j); // (columns nu .. are zero and stay zero)
+                            if (trailing) Lw[i < nx ? LM_X(nx, nu, i, j) : LM_U(nx, nu, i - nx, j)] = mval;
+                            if (lane == 0) S.dinv[t * nu + j] = rinv;
+                        }
+                    }
+                }
+            }
+            if (bad && lane == 0) S.flag[0] = 1; // (wave 0 alone saw the pivots)
+            lds_barrier();
+            FSTAMP(3);
+            // state block on the matrix cores, by the waves that hold its tiles
+#pragma unroll
+            for (int qq = 0; qq < MQ; qq++) {
+                if (have[qq] && lastrow[qq] - 15 < nx && lastcol[qq] - 15 < nx) {
+                    const int i = row0[qq] - r0 + c0, ixc = i < nx ? i : nx - 1, k = colq[qq], kc = k < nx ? k : nx - 1;
+                    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                    acc = mfma_tile_batched<4>(wl, nu,
+                                               [&](int, int j) { return Lw[LM_X(nx, nu, ixc, j)]; },
+                                               [&](int j, int) { return Mf[kc * nz + nx + j]; }, acc);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = row0[qq] + 4 * r, col = colq[qq];
+                        if (row < nx && col <= row) {
+                            const double v = m[qq][r] - acc[r];
+                            Mf[row * nz + col] = v;
+                            Mf[col * nz + row] = v;
+                            fac_pr<D>(S)[t * nxs + sym(row, col)] = v;
+                        }
+                    }
+                }
+            }
+            lds_barrier();
+            if constexpr (D::kBig)
+                for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e];
+            FSTAMP(4);
+            continue;
+        }
         if (nfixed) {
             const int b0 = nx + nuc;
             lds_barrier();
@@ -1222,7 +1309,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         FSTAMP(4);
     }
     __syncthreads(); // (the slab is read by other threads than wrote it: this barrier covers global memory)
-    return bad ? -1 : 0;
+    return (bad || S.flag[0]) ? -1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------------
