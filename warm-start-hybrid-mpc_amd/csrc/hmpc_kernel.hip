@@ -996,44 +996,72 @@ template <int NB, class FA, class FB> DEV mfma_d4 mfma_tile_batched(int wl, int 
     return acc;
 }
 
+// The same for K a multiple of four (uniform trip counts, no clamp or select anywhere): full batches, then single steps.
+template <int NB, class FA, class FB> DEV mfma_d4 mfma_tile_k4(int wl, int K, FA a, FB b, mfma_d4 acc)
+{
+    const int r = wl & 15, kq = wl >> 4;
+    int k0 = 0;
+    for (; k0 + 4 * NB <= K; k0 += 4 * NB) {
+        double av[NB], bv[NB];
+#pragma unroll
+        for (int s = 0; s < NB; s++) { av[s] = a(r, k0 + 4 * s + kq); bv[s] = b(k0 + 4 * s + kq, r); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NB; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[s], acc, 0, 0, 0);
+    }
+    for (; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a(r, k0 + kq), b(k0 + kq, r), acc, 0, 0, 0);
+    return acc;
+}
+
 template <class D> DEV bool factor_tiles_fits(const DevProb &p)
 {
     const int nz = D::nz(p);
-    return D::kNT == 4 * WAVE && nz >= 16 && nz <= 64 && p.mreg < 65536;
+    return D::kNT == 4 * WAVE && nz >= 16 && nz <= 64 && D::nu(p) <= 16 && p.mreg < 65536;
 }
 
+// Wave 0 factorises the PANEL, waves 1 .. 3 (the tile waves) own the tiles.  Per stage, backwards in time:
+//   (1) tile waves: PA = P_{t+1} [A B] on the matrix cores, to LDS                                        | barrier
+//   (2) tile waves: M = G_t + [A B]' PA into their registers (G_t = P + C' D_t C, prepared one stage ahead, see (3));
+//       the input columns of M to LDS (both triangles)                                                    | barrier
+//   (3) wave 0: the elimination.  It only ever reads the input columns of M: the panel M[:, nx .. nz) (nz x nu) is
+//       factorised by wave 0 ALONE, lane i holding row i in registers, the pivot row broadcast with v_readlane -- no
+//       barrier between pivots -- (fixed binaries: identity rows / columns, applied as the panel is loaded).  Out: the
+//       multipliers, the reciprocal pivots, mb, and the panel's columns as they stood when they were the pivot.
+//       MEANWHILE the tile waves prepare G_{t-1}: the Gram part does not depend on the recursion.            | barrier
+//   (4) tile waves: the state block in one step on the matrix cores, P_t = M_xx - L_x A_x' (same operations as
+//       pivot by pivot, each entry's subtractions in the same order), to LDS for (1) and to the slab          | barrier
+// The LDS form above (dense M in LDS, every entry read, updated and written back per pivot by all threads, one barrier
+// per pivot) took 58 k cycles per stage on configs[4]; with one wave per SIMD the cost of a phase is its instruction
+// count, and that form spent it on index arithmetic and on barriers.
 template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
     FSTAMP_DECL;
-    constexpr int MQ = 3; // tiles per wave: nz <= 64 -> 10 lower-triangle tiles over four waves
+    constexpr int MQ = 4;   // tiles per tile wave: nz <= 64 -> 10 lower-triangle tiles over three waves
+    constexpr int NUM = 16; // inputs the panel holds per lane
+    constexpr int NDS = 8;  // steps of four dense rows whose D a lane keeps in registers (more dense rows: the batched loads)
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
     const int wl = lane & 63, wave = __builtin_amdgcn_readfirstlane(lane >> 6), r0 = wl >> 4, c0 = wl & 15; // (wave: uniform, so that everything per tile is scalar)
     const int tn = (nz + 15) >> 4, tx = (nx + 15) >> 4, ntile = tn * (tn + 1) / 2;
+    const bool tilew = wave > 0;
 #ifdef HMPC_STAMPS
     facc[5] += 1; // (count of factorisations)
 #endif
-    ldsd *Mf = S.Mm;           // the matrix as the other lanes see it: dense nz x nz, both triangles
+    ldsd *Mf = S.Mm;           // what the other lanes see of the matrix: dense nz x nz
     ldsd *dump = S.red + 39;   // where the entries of a tile that overhang the matrix are written
-    // this lane's entries: tile qq -> rows row0[qq] + 4 r, column colq[qq]
-    int row0[MQ], colq[MQ];
-    bool have[MQ], offd[MQ], ownw[MQ], mirw[MQ];
-    int lastrow[MQ], lastcol[MQ];
+    // a tile wave's entries: tile qq -> rows row0[qq] + 4 r, column colq[qq]
+    int row0[MQ], colq[MQ], trow[MQ], tcol[MQ];
+    bool have[MQ];
     ldsd *wp[MQ][4], *mp[MQ][4]; // where entry (qq, r) and its mirror image live in Mf
 #pragma unroll
     for (int qq = 0; qq < MQ; qq++) {
-        const int q = wave + 4 * qq;
+        const int q = (wave - 1) + 3 * qq;
         int ti = 0;
         while ((ti + 1) * (ti + 2) / 2 <= q) ti++;
         const int tj = q - ti * (ti + 1) / 2;
-        have[qq] = q < ntile;
-        offd[qq] = have[qq] && ti != tj;
-        // between two pivots only the rows of inputs still to be eliminated are read by other lanes: a tile is written
-        // back where its rows (its mirror image: its columns) reach into them
-        lastrow[qq] = ti * 16 + 15;
-        lastcol[qq] = tj * 16 + 15;
-        ownw[qq] = have[qq] && lastrow[qq] >= nx;
-        mirw[qq] = offd[qq] && lastcol[qq] >= nx;
+        have[qq] = tilew && q < ntile;
+        trow[qq] = ti * 16;
+        tcol[qq] = tj * 16;
         row0[qq] = ti * 16 + r0;
         colq[qq] = tj * 16 + c0;
 #pragma unroll
@@ -1049,263 +1077,200 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         if (i >= j) fac_pr<D>(S)[T * nxs + sym(i, j)] = S.PT[e];
     }
     if (lane == 0) S.flag[0] = 0;
+    const bool dense8 = S.Cdn && p.ndp <= 4 * NDS;
+    // G_t = P + C' D_t C of this lane's tiles (the singleton rows reach the diagonal only; the terminal-set rows, when
+    // they take part, belong to the last stage)
+    double gq[MQ][4];
+    auto gram = [&](int t) {
+        const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
+        const bool term = S.term_on && t == T - 1;
+        double dk[NDS];
+        int ck[NDS]; // row offset of dense row 4 s + kq in Cdn (clamped)
+        if (dense8) {
+#pragma unroll
+            for (int s2 = 0; s2 < NDS; s2++) {
+                const int k = 4 * s2 + r0, kc = k < p.ndp ? k : p.ndp - 1;
+                const double x = Dt[S.drow[kc]];
+                dk[s2] = k < p.ndp ? x : 0.0;
+                ck[s2] = kc * nz;
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < MQ; qq++) {
+            if (have[qq]) {
+                // rows / columns of a tile past nz are read from clamped indices and NOT zeroed: an entry of a product only
+                // sees its own row of the first and its own column of the second operand, and those entries are never used
+                const int i = trow[qq] + c0, ic = i < nz ? i : nz - 1; // first operand: row l & 15 of the tile's rows
+                const int j = colq[qq], jc = j < nz ? j : nz - 1;
+                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                if (dense8) {
+                    double av[NDS], bv[NDS];
+#pragma unroll
+                    for (int s2 = 0; s2 < NDS; s2++) { av[s2] = S.Cdn[ck[s2] + ic] * dk[s2]; bv[s2] = S.Cdn[ck[s2] + jc]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s2 = 0; s2 < NDS; s2++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+                } else if (S.Cdn)
+                    acc = mfma_tile_batched<4>(wl, p.ndp, [&](int, int k) { return S.Cdn[k * nz + ic] * Dt[S.drow[k]]; },
+                                               [&](int k, int) { return S.Cdn[k * nz + jc]; }, acc);
+                else
+                    acc = mfma_tile_batched<5>(wl, p.mreg, [&](int, int k) { return p.Creg[(size_t)k * nz + ic] * Dt[k]; },
+                                               [&](int k, int) { return p.Creg[(size_t)k * nz + jc]; }, acc);
+                if (term) {
+                    const ldsd *De = S.e + p.Toff;
+                    acc = mfma_tile_batched<5>(wl, p.nT, [&](int, int k) { return p.Ct[(size_t)k * nz + ic] * De[k]; },
+                                               [&](int k, int) { return p.Ct[(size_t)k * nz + jc]; }, acc);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = row0[qq] + 4 * r, rc = row < nz ? row : nz - 1;
+                    double v = acc[r] + S.P[rc * nz + jc];
+                    if (S.Cdn && row == j && j < nz) { // diagonal: the singleton rows of this column
+                        for (int k = S.sptr[j]; k < S.sptr[j + 1]; k++) {
+                            const int sr = S.srow[k];
+                            const double c = S.sval[sr];
+                            v += c * c * Dt[sr];
+                        }
+                    }
+                    gq[qq][r] = v;
+                }
+            }
+        }
+    };
+    gram(T - 1);
     int bad = 0;
     for (int t = T - 1; t >= 0; t--) {
         const ldsd *Pn = t == T - 1 ? S.PT : Mf; // P_{t+1}: the terminal Hessian, or the block the previous stage left
         const int pns = t == T - 1 ? nx : nz;
         const ldsi *fx = S.fix + t * nub;
         const auto Lm = fac_lm<D>(S) + t * lms;
-        int nfixed = 0;
-        for (int b = 0; b < nub; b++) nfixed += fx[b] >= 0;
-        // diagonal of C' D C from the singleton rows (S.mv is free during a factorisation), read after the barrier below
-        if (S.Cdn && lane < nz) {
-            const ldsd *Dq = S.e + t * p.mreg;
-            double a = 0;
-            for (int k = S.sptr[lane]; k < S.sptr[lane + 1]; k++) {
-                const int sr = S.srow[k];
-                const double c = S.sval[sr];
-                a += c * c * Dq[sr];
-            }
-            S.mv[lane] = a;
-        }
+        ldsd *Lw;
+        if constexpr (D::kBig) Lw = S.Lw;
+        else Lw = S.Lm + t * lms;
         // (1) PA = P_{t+1} [A B]  (nx x nz)
-        for (int q = wave; q < tx * tn; q += D::kNW) {
-            const int ti = q / tn, tj = q - ti * tn;
-            const int i = ti * 16 + c0, ic = i < nx ? i : nx - 1, j = tj * 16 + c0, jc = j < nz ? j : nz - 1;
-            mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-            acc = mfma_tile_batched<5>(wl, nx,
-                                       [&](int, int k) { return Pn[ic * pns + k]; },
-                                       [&](int k, int) { return S.AB[k * AB_STRIDE + jc]; }, acc);
+        if (tilew) {
+            for (int q = wave - 1; q < tx * tn; q += 3) {
+                const int ti = q / tn, tj = q - ti * tn;
+                const int i = ti * 16 + c0, ic = i < nx ? i : nx - 1, j = tj * 16 + c0, jc = j < nz ? j : nz - 1;
+                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                if ((nx & 3) == 0)
+                    acc = mfma_tile_k4<5>(wl, nx, [&](int, int k) { return Pn[ic * pns + k]; }, [&](int k, int) { return S.AB[k * AB_STRIDE + jc]; }, acc);
+                else
+                    acc = mfma_tile_batched<5>(wl, nx, [&](int, int k) { return Pn[ic * pns + k]; },
+                                               [&](int k, int) { return S.AB[k * AB_STRIDE + jc]; }, acc);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ii = ti * 16 + r0 + 4 * r;
-                if (ii < nx && j < nz) S.PA[ii * nz + j] = acc[r];
+                for (int r = 0; r < 4; r++) {
+                    const int ii = ti * 16 + r0 + 4 * r;
+                    if (ii < nx && j < nz) S.PA[ii * nz + j] = acc[r];
+                }
             }
         }
+        for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
         lds_barrier();
-        // (2) the tiles of M, in registers.  Rows / columns of a tile past nz are read from clamped indices and NOT zeroed:
-        // an entry of the product only sees its own row of the first and its own column of the second operand, and the
-        // entries past nz are never used.
+        FSTAMP(0);
+        // (2) the tiles of M, in registers; their input columns to LDS
         double m[MQ][4];
-        const ldsd *Dt = S.e + t * p.mreg; // S.e holds D during the factorisation
-        const bool term = S.term_on && t == T - 1;
 #pragma unroll
         for (int qq = 0; qq < MQ; qq++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) m[qq][r] = 0.0;
             if (have[qq]) {
-                const int i = row0[qq] - r0 + c0, ic = i < nz ? i : nz - 1; // A operand: row l & 15 of the tile's rows
-                const int j = colq[qq], jc = j < nz ? j : nz - 1;
-                const double sdg = S.Cdn ? S.mv[jc] : 0.0;
-                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                if (S.Cdn) // the dense rows; the singleton rows only reach the diagonal (sdg)
-                    acc = mfma_tile_batched<4>(wl, p.ndp,
-                                               [&](int, int k) { return S.Cdn[k * nz + ic] * Dt[S.drow[k]]; },
-                                               [&](int k, int) { return S.Cdn[k * nz + jc]; }, acc);
+                const int i = trow[qq] + c0, ic = i < nz ? i : nz - 1, jc = colq[qq] < nz ? colq[qq] : nz - 1;
+                mfma_d4 acc = {gq[qq][0], gq[qq][1], gq[qq][2], gq[qq][3]};
+                if ((nx & 3) == 0)
+                    acc = mfma_tile_k4<5>(wl, nx, [&](int, int k) { return S.AB[k * AB_STRIDE + ic]; }, [&](int k, int) { return S.PA[k * nz + jc]; }, acc);
                 else
-                    acc = mfma_tile_batched<5>(wl, p.mreg,
-                                               [&](int, int k) { const double v = p.Creg[(size_t)k * nz + ic] * Dt[k]; return i < nz ? v : 0.0; },
-                                               [&](int k, int) { const double v = p.Creg[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
-                if (term) {
-                    const ldsd *De = S.e + p.Toff;
-                    acc = mfma_tile_batched<5>(wl, p.nT,
-                                               [&](int, int k) { const double v = p.Ct[(size_t)k * nz + ic] * De[k]; return i < nz ? v : 0.0; },
-                                               [&](int k, int) { const double v = p.Ct[(size_t)k * nz + jc]; return j < nz ? v : 0.0; }, acc);
-                }
-                acc = mfma_tile_batched<5>(wl, nx,
-                                           [&](int, int k) { return S.AB[k * AB_STRIDE + ic]; },
-                                           [&](int k, int) { return S.PA[k * nz + jc]; }, acc);
+                    acc = mfma_tile_batched<5>(wl, nx, [&](int, int k) { return S.AB[k * AB_STRIDE + ic]; },
+                                               [&](int k, int) { return S.PA[k * nz + jc]; }, acc);
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = row0[qq] + 4 * r, rc = row < nz ? row : nz - 1;
-                    m[qq][r] = acc[r] + S.P[rc * nz + jc] + (row == j ? sdg : 0.0);
-                }
-            }
-        }
-        // every lane writes all its entries, no predicate: the addresses were fixed once (overhang -> dump slot)
-        auto publish = [&]() {
-#pragma unroll
-            for (int qq = 0; qq < MQ; qq++) {
-                if (have[qq]) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) *wp[qq][r] = m[qq][r];
-                    if (offd[qq]) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) *mp[qq][r] = m[qq][r];
-                    }
-                }
-            }
-        };
-        publish(); // (P_{t+1} in Mf was last read in (1), before the barrier every wave has passed)
-        FSTAMP(0);
-        // (3) fixed binaries: mb = sum of the columns of the binaries fixed to one, then identity rows / columns
-        ldsd *Lw;
-        if constexpr (D::kBig) Lw = S.Lw;
-        else Lw = S.Lm + t * lms;
-        for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
-        constexpr int NUM = 16; // inputs the panel form holds per lane
-        if (nu <= NUM) {
-            // PANEL FORM.  The elimination only ever reads the input columns of M: the panel M[:, nx .. nz) (nz x nu) is
-            // factorised by wave 0 ALONE, lane i holding row i in registers, the pivot row broadcast with v_readlane -- no
-            // barrier between pivots, a third of the instructions of the tile form below --, and the state block follows in
-            // one step on the matrix cores:  P_t = M_xx - L_x A_x'  (A_x: the panel's state rows as they stood when their
-            // column was the pivot; same operations as pivot-by-pivot, each entry's subtractions in the same order).
-            lds_barrier(); // M as published, Lw zeroed
-            if (lane < WAVE) {
-                const int i = lane, ic = i < nz ? i : 0, b0 = nx + nuc;
-                unsigned fixmask = 0; // bit k: input k is a binary the node fixes (wave uniform)
-                for (int b = 0; b < nub; b++)
-                    if (fx[b] >= 0) fixmask |= 1u << (nuc + b);
-                fixmask = __builtin_amdgcn_readfirstlane(fixmask);
-                if (i < nz) {
-                    double g = 0;
-                    if (nfixed)
-                        for (int b = 0; b < nub; b++)
-                            if (fx[b] == 1) g += Mf[i * nz + b0 + b];
-                    S.g[t * nz + i] = g;
-                }
-                const bool rowfixed = i >= nx && i < nz && ((fixmask >> (i - nx)) & 1u);
-                double a[NUM];
-#pragma unroll
-                for (int k = 0; k < NUM; k++) {
-                    const double x = Mf[ic * nz + nx + (k < nu ? k : 0)];
-                    const bool pres = rowfixed || ((fixmask >> k) & 1u); // prescribed component: identity row / column
-                    a[k] = (k < nu && i < nz) ? (pres ? (i == nx + k ? 1.0 : 0.0) : x) : 0.0;
-                }
-                // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
-                // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
-                int nuo = nu;
-#pragma unroll
-                for (int j = 0; j < NUM; j++) {
-                    asm volatile("" : "+s"(nuo), "+s"(fixmask));
-                    if (j < nuo) {
-                        if (i < nz) Mf[i * nz + nx + j] = a[j]; // the column as it stands: second operand of the state block's product
-                        if ((fixmask >> j) & 1u) { // decoupled unit pivot: the solves skip it as well
-                            if (lane == 0) S.dinv[t * nu + j] = 1.0;
-                        } else {
-                            const double d = bcast(a[j], nx + j);
-                            if (!(d > 0.0)) bad = 1;
-                            double rinv = __builtin_amdgcn_rcp(d);
-                            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
-                            const bool trailing = i < nx || (i > nx + j && i < nz);
-                            const double mval = a[j] * rinv, meff = trailing ? mval : 0.0;
-#pragma unroll
-                            for (int k = j + 1; k < NUM; k++) a[k] -= meff * bcast(a[k], nx + j); // (columns nu .. are zero and stay zero)
-                            if (trailing) Lw[i < nx ? LM_X(nx, nu, i, j) : LM_U(nx, nu, i - nx, j)] = mval;
-                            if (lane == 0) S.dinv[t * nu + j] = rinv;
-                        }
-                    }
-                }
-            }
-            if (bad && lane == 0) S.flag[0] = 1; // (wave 0 alone saw the pivots)
-            lds_barrier();
-            FSTAMP(3);
-            // state block on the matrix cores, by the waves that hold its tiles
-#pragma unroll
-            for (int qq = 0; qq < MQ; qq++) {
-                if (have[qq] && lastrow[qq] - 15 < nx && lastcol[qq] - 15 < nx) {
-                    const int i = row0[qq] - r0 + c0, ixc = i < nx ? i : nx - 1, k = colq[qq], kc = k < nx ? k : nx - 1;
-                    mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                    acc = mfma_tile_batched<4>(wl, nu,
-                                               [&](int, int j) { return Lw[LM_X(nx, nu, ixc, j)]; },
-                                               [&](int j, int) { return Mf[kc * nz + nx + j]; }, acc);
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = row0[qq] + 4 * r, col = colq[qq];
-                        if (row < nx && col <= row) {
-                            const double v = m[qq][r] - acc[r];
-                            Mf[row * nz + col] = v;
-                            Mf[col * nz + row] = v;
-                            fac_pr<D>(S)[t * nxs + sym(row, col)] = v;
-                        }
-                    }
-                }
-            }
-            lds_barrier();
-            if constexpr (D::kBig)
-                for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e];
-            FSTAMP(4);
-            continue;
-        }
-        if (nfixed) {
-            const int b0 = nx + nuc;
-            lds_barrier();
-            for (int i = lane; i < nz; i += D::kNT) {
-                double a = 0;
-                for (int b = 0; b < nub; b++)
-                    if (fx[b] == 1) a += Mf[i * nz + b0 + b];
-                S.g[t * nz + i] = a;
-            }
-#pragma unroll
-            for (int qq = 0; qq < MQ; qq++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int row = row0[qq] + 4 * r, col = colq[qq];
-                    const bool fi = row >= b0 && row < nz && fx[row - b0] >= 0;
-                    const bool fj = col >= b0 && col < nz && fx[col - b0] >= 0;
-                    if (fi || fj) m[qq][r] = (row == col) ? 1.0 : 0.0;
-                }
-            }
-            lds_barrier();
-            publish();
-        } else {
-            for (int i = lane; i < nz; i += D::kNT) S.g[t * nz + i] = 0.0;
-        }
-        FSTAMP(2);
-        // (4) elimination of the inputs: per pivot, read the pivot row from Mf, update the registers, write them back
-        for (int j = 0; j < nu; j++) {
-            if (j >= nuc && fx[j - nuc] >= 0) { // decoupled unit pivot: the solves skip it as well
-                if (lane == 0) S.dinv[t * nu + j] = 1.0;
-                continue;
-            }
-            const int pj = nx + j;
-            const ldsd *v = Mf + pj * nz;
-            lds_barrier(); // the entries written after the previous step are visible
-            const double d = v[pj];
-            if (!(d > 0.0)) bad = 1;
-            double rinv = __builtin_amdgcn_rcp(d);
-            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
-#pragma unroll
-            for (int qq = 0; qq < MQ; qq++) {
-                if (have[qq]) {
-                    const double vc = v[colq[qq]]; // (an index past nz reads inside the scratch block; the entry is never used)
-                    double vr[4];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) vr[r] = v[row0[qq] + 4 * r];
-#pragma unroll
-                    for (int r = 0; r < 4; r++) m[qq][r] -= (vr[r] * rinv) * vc;
-                }
-            }
-            if (lane < nz && (lane < nx || lane > pj))
-                Lw[lane < nx ? LM_X(nx, nu, lane, j) : LM_U(nx, nu, lane - nx, j)] = v[lane] * rinv;
-            if (lane == 0) S.dinv[t * nu + j] = rinv;
-            lds_barrier(); // every lane has read the pivot row
-#pragma unroll
-            for (int qq = 0; qq < MQ; qq++) {
-                if (ownw[qq] && lastrow[qq] > pj) {
+                for (int r = 0; r < 4; r++) m[qq][r] = acc[r];
+                // (P_{t+1} in Mf was last read in (1), before the barrier every wave has passed; the state block of M stays
+                // in registers: only the input columns are read by others)
+                if (tcol[qq] + 15 >= nx) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) *wp[qq][r] = m[qq][r];
                 }
-                if (mirw[qq] && lastcol[qq] > pj) {
+                if (trow[qq] != tcol[qq] && trow[qq] + 15 >= nx) {
 #pragma unroll
                     for (int r = 0; r < 4; r++) *mp[qq][r] = m[qq][r];
                 }
             }
         }
-        publish(); // all of it: the leading block is P_t, read by the next stage's product
-        FSTAMP(3);
-        // (5) P_t: the leading block of Mf for the next stage's product, packed for the solves
-#pragma unroll
-        for (int qq = 0; qq < MQ; qq++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = row0[qq] + 4 * r, col = colq[qq];
-                if (have[qq] && row < nx && col <= row) fac_pr<D>(S)[t * nxs + sym(row, col)] = m[qq][r];
+        lds_barrier();
+        FSTAMP(1);
+        // (3) wave 0: mb and the panel; tile waves: the Gram part of the next stage
+        if (!tilew) {
+            const int i = lane, ic = i < nz ? i : 0, b0 = nx + nuc;
+            const int fxv = i < nub ? fx[i < nub ? i : 0] : -1;
+            const unsigned long long fm1 = __ballot(fxv >= 0), fone = __ballot(fxv == 1);
+            unsigned fixmask = (unsigned)(fm1 << nuc); // bit k: input k is a binary the node fixes (wave uniform)
+            if (i < nz) {
+                double g = 0;
+                for (int b = 0; b < nub; b++)
+                    if ((fone >> b) & 1ull) g += Mf[i * nz + b0 + b];
+                S.g[t * nz + i] = g;
             }
+            const bool rowfixed = i >= nx && i < nz && ((fixmask >> (i - nx)) & 1u);
+            double a[NUM];
+#pragma unroll
+            for (int k = 0; k < NUM; k++) {
+                const double x = Mf[ic * nz + nx + (k < nu ? k : 0)];
+                const bool pres = rowfixed || ((fixmask >> k) & 1u); // prescribed component: identity row / column
+                a[k] = (k < nu && i < nz) ? (pres ? (i == nx + k ? 1.0 : 0.0) : x) : 0.0;
+            }
+            // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
+            // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
+            int nuo = nu;
+#pragma unroll
+            for (int j = 0; j < NUM; j++) {
+                asm volatile("" : "+s"(nuo), "+s"(fixmask));
+                if (j < nuo) {
+                    if (i < nz) Mf[i * nz + nx + j] = a[j]; // the column as it stands: second operand of the state block's product
+                    if ((fixmask >> j) & 1u) { // decoupled unit pivot: the solves skip it as well
+                        if (lane == 0) S.dinv[t * nu + j] = 1.0;
+                    } else {
+                        const double d = bcast(a[j], nx + j);
+                        if (!(d > 0.0)) bad = 1;
+                        double rinv = __builtin_amdgcn_rcp(d);
+                        rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
+                        const bool trailing = i < nx || (i > nx + j && i < nz);
+                        const double mval = a[j] * rinv, meff = trailing ? mval : 0.0;
+#pragma unroll
+                        for (int k = j + 1; k < NUM; k++) a[k] -= meff * bcast(a[k], nx + j); // (columns nu .. are zero and stay zero)
+                        if (trailing) Lw[i < nx ? LM_X(nx, nu, i, j) : LM_U(nx, nu, i - nx, j)] = mval;
+                        if (lane == 0) S.dinv[t * nu + j] = rinv;
+                    }
+                }
+            }
+            if (bad && lane == 0) S.flag[0] = 1; // (wave 0 alone sees the pivots)
+        } else if (t > 0) {
+            gram(t - 1);
         }
         lds_barrier();
+        FSTAMP(3);
+        // (4) state block on the matrix cores, by the waves that hold its tiles
+#pragma unroll
+        for (int qq = 0; qq < MQ; qq++) {
+            if (have[qq] && trow[qq] < nx && tcol[qq] < nx) {
+                const int i = trow[qq] + c0, ixc = i < nx ? i : nx - 1, k = colq[qq], kc = k < nx ? k : nx - 1;
+                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                acc = mfma_tile_batched<4>(wl, nu, [&](int, int j) { return Lw[LM_X(nx, nu, ixc, j)]; },
+                                           [&](int j, int) { return Mf[kc * nz + nx + j]; }, acc);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = row0[qq] + 4 * r, col = colq[qq];
+                    if (row < nx && col <= row) {
+                        const double v = m[qq][r] - acc[r];
+                        Mf[row * nz + col] = v;
+                        Mf[col * nz + row] = v;
+                        fac_pr<D>(S)[t * nxs + sym(row, col)] = v;
+                    }
+                }
+            }
+        }
         if constexpr (D::kBig)
-            for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e];
+            for (int e = lane; e < lms; e += D::kNT) Lm[e] = Lw[e]; // (written in (3), before the last barrier)
+        lds_barrier();
         FSTAMP(4);
     }
     __syncthreads(); // (the slab is read by other threads than wrote it: this barrier covers global memory)
@@ -1574,7 +1539,12 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
         double a = 0.0;
         if (csrc) {
             const auto Pn = fac_pr<D>(S) + (t + 1) * nxs;
-            for (int l = 0; l < nx; l++) a += Pn[sym(i, l)] * (cs * csrc[t * nx + l]);
+            int l = 0;
+            for (; l + 4 <= nx; l += 4) { // (four loads of the slab in flight: a load inside the sum that uses it waits for itself)
+                const double p0 = Pn[sym(i, l)], p1 = Pn[sym(i, l + 1)], p2 = Pn[sym(i, l + 2)], p3 = Pn[sym(i, l + 3)];
+                a += p0 * (cs * csrc[t * nx + l]) + p1 * (cs * csrc[t * nx + l + 1]) + p2 * (cs * csrc[t * nx + l + 2]) + p3 * (cs * csrc[t * nx + l + 3]);
+            }
+            for (; l < nx; l++) a += Pn[sym(i, l)] * (cs * csrc[t * nx + l]);
         }
         S.pv[o] = a;
     }
@@ -1967,7 +1937,13 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     for (int o = lane; o < (T + 1) * nx; o += D::kNT) {
         const int t = o / nx, i = o - t * nx;
         double a = S.pv[o];
-        for (int l = 0; l < nx; l++) a += fac_pr<D>(S)[t * nxs + sym(i, l)] * dw[t * nz + l];
+        const auto Pt = fac_pr<D>(S) + t * nxs;
+        int l = 0;
+        for (; l + 4 <= nx; l += 4) { // (as in the prepass of the sweeps: four loads of the slab in flight)
+            const double p0 = Pt[sym(i, l)], p1 = Pt[sym(i, l + 1)], p2 = Pt[sym(i, l + 2)], p3 = Pt[sym(i, l + 3)];
+            a += p0 * dw[t * nz + l] + p1 * dw[t * nz + l + 1] + p2 * dw[t * nz + l + 2] + p3 * dw[t * nz + l + 3];
+        }
+        for (; l < nx; l++) a += Pt[sym(i, l)] * dw[t * nz + l];
         dlam[o] = -a;
     }
     FSTAMP(8);
