@@ -309,6 +309,13 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
                 sptr[j + 1] = (int)srow.size();
             }
             p.ns = (int)srow.size();
+            std::vector<int> nrow;
+            for (int r = 0; r < p.mreg; r++)
+                if (rinfo[r] >= 0) nrow.push_back(r);
+            p.nd_magic = p.nd > 0 ? (unsigned)((0x100000000ULL + p.nd - 1) / p.nd) : 0u;
+            p.nn_magic = !nrow.empty() ? (unsigned)((0x100000000ULL + nrow.size() - 1) / nrow.size()) : 0u;
+            if (nrow.empty()) nrow.push_back(0);
+            if ((rc = upload(h, nrow, &p.nrow))) break;
             if (Cdn.empty()) Cdn.push_back(0.0);
             if (drow.empty()) drow.push_back(0);
             if (srow.empty()) srow.push_back(0);

@@ -48,6 +48,8 @@ struct DevProb {
     const int *rinfo;                          // mreg: singleton row -> its column; dense row k -> -(k + 1)
     const double *sval;                        // mreg: coefficient of a singleton row
     const int *sptr, *srow;                    // singleton rows by column: sptr[nz + 1], srow[ns]
+    const int *nrow;                           // the rows that are not dense, in row order (mreg - nd)
+    unsigned nd_magic, nn_magic;               // ceil(2^32 / nd), ceil(2^32 / (mreg - nd)): divisions of a row position (as mreg_magic)
     int split_lds;
     int static_rows;                           // every [F G] row has at most two nonzero input coefficients
     const double *Ct, *ht, *sct;               // terminal-set rows of the last stage: dense nT x nz, rhs, row scales
@@ -113,7 +115,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
     }
     if (kc == 0 && p.split_lds) {                                          // split stage rows (dense block, singleton lists)
         d += (size_t)p.ndp * nz + p.mreg;
-        i += (size_t)p.ndp + p.mreg + (nz + 1) + p.ns;
+        i += (size_t)p.ndp + p.mreg + (nz + 1) + p.ns + (p.mreg - p.nd);
     }
     return d * sizeof(double) + i * sizeof(int) + b;
 }

@@ -228,7 +228,7 @@ struct Lds {
     // generic kernel, nz >= 16 (DevProb::split_lds; Cdn null otherwise): dense stage rows (ndp x nz), their local rows,
     // per row: singleton column or -(dense index + 1), singleton coefficient; singleton rows by column
     const ldsd *Cdn, *sval;
-    const ldsi *drow, *rinfo, *sptr, *srow;
+    const ldsi *drow, *rinfo, *sptr, *srow, *nrow; // (nrow: the rows that are not dense, mreg - nd of them)
     const ldsd *ccv;   // compile-time shapes: the columns of the stage rows padded to kKC entries each
     const ldsb *cci;   //   (value, local row); the row lists are not staged at all (RowMapS holds rows in registers)
     int term_on;       // terminal-set rows active in the current solve
@@ -558,13 +558,43 @@ template <class D> DEV double hrow(const DevProb &p, const Lds &S, int lr) { ret
 template <class D> struct RowMapL {
     struct Ref { int e, t, lr; };
     static constexpr int kSlots = 0;
-    DEV void init(const DevProb &, int) {}
+    const ldsi *drow, *nrow; // streaming form with split stage rows: dense rows, the other rows (null: rows in their own order)
+    DEV void init(const DevProb &, int) { drow = nullptr; nrow = nullptr; }
+    DEV void bind(const DevProb &p, const Lds &S)
+    {
+        if constexpr (D::kBig) {
+            if (p.split_lds) { drow = S.drow; nrow = S.nrow; }
+        }
+    }
     DEV void prepare(const DevProb &, const Lds &, int, int) {}
     DEV bool at(const DevProb &p, int k, int lane, Ref &rw) const
     {
         int r = k * D::kNT + lane;
         ROW_OPAQUE(r);
         if (r >= p.M) return false;
+        if constexpr (D::kBig) {
+            if (drow) {
+                // Positions are dealt so that a wave's 64 rows are of one kind: first the dense rows of all stages (a product
+                // with a dense row is ~nz terms), then the others (one term) -- in row order every wave held some dense
+                // rows and ran the long form in every slot.  Terminal-set rows keep their places at the end.
+                const int nds = p.T * p.nd;
+                if (r < nds) {
+                    const int t = (int)__umulhi((unsigned)r, p.nd_magic);
+                    rw.t = t;
+                    rw.lr = drow[r - t * p.nd];
+                    rw.e = t * p.mreg + rw.lr;
+                    return true;
+                }
+                if (r < p.Toff) {
+                    const int q = r - nds, nn = p.mreg - p.nd;
+                    const int t = (int)__umulhi((unsigned)q, p.nn_magic);
+                    rw.t = t;
+                    rw.lr = nrow[q - t * nn];
+                    rw.e = t * p.mreg + rw.lr;
+                    return true;
+                }
+            }
+        }
         rw.e = r;
         row_decode(p, r, rw.t, rw.lr);
         return true;
@@ -578,6 +608,7 @@ template <class D> struct RowMapL {
 };
 
 template <class D, int KF, int KB, int KT> struct RowMapS {
+    DEV void bind(const DevProb &, const Lds &) {}
     static constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
     static constexpr int kSlots = KF + KB + KT, kSlotsFB = KF + KB;
     static constexpr int SB = D::kNT / (2 * NUB); // stages per slot of bound rows
@@ -3112,7 +3143,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         ldsi *rptr0 = takei(NL ? 0 : p.mreg + 1), *rcol0 = takei(NL ? 0 : p.nnz0), *cptr0 = takei(NL ? 0 : nz + 1);
         ldsi *crow0 = takei(NL ? 0 : p.nnz0);
         ldsi *gptr0 = takei(D::kBig ? 0 : ne + 1), *grow0 = takei(D::kBig ? 0 : p.nng0);
-        ldsi *drow0 = takei(p.split_lds ? p.ndp : 0), *rinfo0 = takei(p.split_lds ? p.mreg : 0), *sptr0 = takei(p.split_lds ? nz + 1 : 0), *srow0 = takei(p.split_lds ? p.ns : 0);
+        ldsi *drow0 = takei(p.split_lds ? p.ndp : 0), *rinfo0 = takei(p.split_lds ? p.mreg : 0), *sptr0 = takei(p.split_lds ? nz + 1 : 0), *srow0 = takei(p.split_lds ? p.ns : 0), *nrow0 = takei(p.split_lds ? p.mreg - p.nd : 0);
         ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
@@ -3149,13 +3180,14 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         S.G0 = ListsG{g0.rptr, g0.rcol, g0.cptr, g0.crow, g0.gptr, g0.grow, g0.rval, g0.cval, g0.gval, g0.h};
         S.ccv = cval0;
         S.Cdn = p.split_lds ? cdn0 : nullptr;
-        S.sval = sval0; S.drow = drow0; S.rinfo = rinfo0; S.sptr = sptr0; S.srow = srow0;
+        S.sval = sval0; S.drow = drow0; S.rinfo = rinfo0; S.sptr = sptr0; S.srow = srow0; S.nrow = nrow0;
         if (p.split_lds) {
             for (int i = lane; i < p.ndp * nz; i += D::kNT) cdn0[i] = p.Cdn[i];
             for (int i = lane; i < p.mreg; i += D::kNT) { sval0[i] = p.sval[i]; rinfo0[i] = p.rinfo[i]; }
             for (int i = lane; i < p.ndp; i += D::kNT) drow0[i] = p.drow[i];
             for (int i = lane; i < nz + 1; i += D::kNT) sptr0[i] = p.sptr[i];
             for (int i = lane; i < p.ns; i += D::kNT) srow0[i] = p.srow[i];
+            for (int i = lane; i < p.mreg - p.nd; i += D::kNT) nrow0[i] = p.nrow[i];
         }
         S.cci = cci0;
         S.term_on = 0;
@@ -3165,6 +3197,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     R.bind(rows_ws + (size_t)blockIdx.x * 4 * p.Mpad, p.Mpad);
     RM rm;
     rm.init(p, lane);
+    rm.bind(p, S);
     // Nodes differ in work (7 to 25 interior-point iterations, a second solve when the terminal set binds): the
     // first gridDim.x nodes go to the workgroups by index, every further node to the first workgroup that is free
     // (one atomic per node on a counter the host zeroes before the launch).  A record does not depend on the
