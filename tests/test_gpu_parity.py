@@ -24,7 +24,19 @@ RTOL = 1e-5   # north_star: continuous trajectories within 1e-5 relative -- ONE 
 
 
 ETOL, EFLOOR = 1e-5, 1e-6   # element-wise: every component within 1e-5 of its own size (components below 1e-6: of 1e-6)
-WORST = {'norm': 0.0, 'element': 0.0, 'dense': 0.0}   # largest deviations seen in this session (printed at the end)
+# Records WITHOUT the polished flag (HMPC_ITERS_POLISHED clear: the active-set polish did not verify, the record is the
+# interior-point iterate that met the stopping test -- a documented, distinct outcome, include/hmpc.h) are only
+# reproducible to the accuracy of such an iterate.  With the barrier parameter at its floor (mu < 1e-11, exit
+# "exhausted") the objective is within ~1e-6 relative of the optimum; for a cost of curvature 2 (Q = I, R = [I 0]: the
+# random MLD) two such points may lie 2 sqrt(eps) ~ 4e-3 apart, and two runs of the SAME algorithm whose sums are
+# associated differently (kernel and oracle, or two versions of the kernel) do end 1e-5 .. 1.4e-4 apart -- measured on
+# the dive frontier of BASELINE configs[4], the one configuration where a quarter of the optimal nodes end that way
+# (round 2's kernel: 3.1e-5 on 96 nodes; its 48-node test passed at 1e-5 by the luck of the sample).  Such records are
+# held to: the same status, objectives within 2e-6, a KKT certificate of their own at 2e-6 (kkt_checks.check_solution:
+# feasible, dual feasible, duality gap -- no reference involved), and trajectories within 1e-3 norm-wise of the
+# oracle's.  Every polished record -- all optimal nodes of the cart-pole systems -- is held to RTOL element-wise.
+ITERATE_RTOL = 1e-3
+WORST = {'norm': 0.0, 'element': 0.0, 'dense': 0.0, 'iterate': 0.0}   # largest deviations seen in this session (printed at the end)
 
 
 def _rel(a, b, elementwise=True):
@@ -35,9 +47,10 @@ def _rel(a, b, elementwise=True):
         return np.zeros(a.shape[0])
     scale = np.maximum(1e-2, np.max(np.abs(b), axis=1, keepdims=True))
     norm = np.max(np.abs(a - b) / scale, axis=1)
-    WORST['norm'] = max(WORST['norm'], norm.max())
     if not elementwise:
+        WORST['iterate'] = max(WORST['iterate'], norm.max())   # (records without the polished flag)
         return norm
+    WORST['norm'] = max(WORST['norm'], norm.max())
     elem = np.max(np.abs(a - b) / np.maximum(np.abs(b), EFLOOR), axis=1)
     WORST['element'] = max(WORST['element'], elem.max())
     return np.maximum(norm, elem * (RTOL / ETOL))
@@ -50,7 +63,8 @@ _DENSE = {}
 def _report_worst_deviations():
     yield
     line = ('parity margins of this run: kernel vs oracle norm-wise %.2e, element-wise (floor %.0e) %.2e; kernel vs dense '
-            'active-set solve %.2e' % (WORST['norm'], EFLOOR, WORST['element'], WORST['dense']))
+            'active-set solve %.2e; unpolished records (interior-point iterates) norm-wise %.2e'
+            % (WORST['norm'], EFLOOR, WORST['element'], WORST['dense'], WORST['iterate']))
     print('\n' + line)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(out):
@@ -79,7 +93,7 @@ def _dense_check(ctrl, T, x0, fix, rec, sample=64, seed=0):
     return opt.size
 
 
-def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True):
+def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True, RTOL=RTOL):
     """States, the inputs the cost is strictly convex in (unique at every node), and -- where every binary is
     fixed, the nodes an incumbent comes from -- ALL inputs, at RTOL.  Inputs no cost term sees are not unique in
     a relaxation: a vertex solution and Gurobi's would differ there as well."""
@@ -117,7 +131,8 @@ def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
     if min_polished is not None:
         assert pol.sum() >= min_polished * fin.sum(), (pol.sum(), fin.sum())
     _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[pol], a['primal'][pol], b['primal'][pol], 'polished')
-    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[raw], a['primal'][raw], b['primal'][raw], 'iterate', elementwise=False)
+    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[raw], a['primal'][raw], b['primal'][raw], 'iterate', elementwise=False,
+                        RTOL=ITERATE_RTOL)
     inf = a['status'] == 1
     assert np.all(np.isinf(a['obj'][inf])) and np.all(np.isnan(a['primal'][inf]))
     # Farkas rays are normalised to a unit largest multiplier on both sides
@@ -369,8 +384,8 @@ def test_streaming_kernel_baseline_config4():
         assert r['status'][0] == 0
         leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
     rng = np.random.default_rng(0)
-    fix = np.full((48, T * nub), -1, np.int8)
-    for k in range(1, 48):
+    fix = np.full((256, T * nub), -1, np.int8)
+    for k in range(1, 256):
         d = int(rng.integers(1, T * nub + 1))
         fix[k, :d] = leaf[0, :d]
         if k % 2 == 0:
@@ -381,6 +396,13 @@ def test_streaming_kernel_baseline_config4():
     # this generator leaves the binaries out of the cost (R = [I 0], as the reference does): states and continuous
     # inputs are unique and compared at RTOL like everywhere else, the relaxed binaries are not
     _compare(ctrl, a, b, T, fix, min_polished=0.6)   # (the active sets of this generator's relaxations are hard: 6 rounds x 3 attempts)
+    # the records that are NOT polished certify themselves (no reference involved): feasible, dual feasible, duality gap
+    raw = np.flatnonzero((a['status'] == 0) & (a['polished'] == 0))
+    assert raw.size > 0
+    for i in raw:
+        sol = SubproblemSolution.from_rows(ctrl.layout, fix[i], a['obj'][i], a['dual_obj'][i], a['status'][i], a['primal'][i], a['dual'][i])
+        ident = {(k // nub, k % nub): float(v) for k, v in enumerate(fix[i]) if v >= 0}
+        assert check_solution(ctrl, sol, ident, x0, tol=2e-6) == 'optimal'
     assert (a['status'] == 0).sum() >= 1 and (a['status'] == 1).sum() >= 1
     # a problem whose vectors alone exceed a CU's LDS is still refused loudly
     huge = HybridModelPredictiveController(mld, 60, objective, None, backend=_NoBackend())

@@ -1044,6 +1044,33 @@ template <int NB, class FA, class FB> DEV mfma_d4 mfma_tile_k4(int wl, int K, FA
     return acc;
 }
 
+// Two tiles at once, K a multiple of four: their products alternate, so that the accumulate of one tile does not wait for
+// the result of its own previous step (a matrix-core instruction that depends on the one before it waits out its latency).
+template <int NB, class FA0, class FB0, class FA1, class FB1>
+DEV void mfma_pair_k4(int wl, int K, FA0 a0, FB0 b0, FA1 a1, FB1 b1, mfma_d4 &acc0, mfma_d4 &acc1)
+{
+    const int r = wl & 15, kq = wl >> 4;
+    int k0 = 0;
+    for (; k0 + 4 * NB <= K; k0 += 4 * NB) {
+        double av0[NB], bv0[NB], av1[NB], bv1[NB];
+#pragma unroll
+        for (int s = 0; s < NB; s++) {
+            av0[s] = a0(r, k0 + 4 * s + kq); bv0[s] = b0(k0 + 4 * s + kq, r);
+            av1[s] = a1(r, k0 + 4 * s + kq); bv1[s] = b1(k0 + 4 * s + kq, r);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NB; s++) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[s], bv0[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[s], bv1[s], acc1, 0, 0, 0);
+        }
+    }
+    for (; k0 < K; k0 += 4) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0(r, k0 + kq), b0(k0 + kq, r), acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1(r, k0 + kq), b1(k0 + kq, r), acc1, 0, 0, 0);
+    }
+}
+
 template <class D> DEV bool factor_tiles_fits(const DevProb &p)
 {
     const int nz = D::nz(p);
@@ -1180,7 +1207,24 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         else Lw = S.Lm + t * lms;
         // (1) PA = P_{t+1} [A B]  (nx x nz)
         if (tilew) {
-            for (int q = wave - 1; q < tx * tn; q += 3) {
+            int q = wave - 1;
+            if ((nx & 3) == 0) {
+                for (; q + 3 < tx * tn; q += 6) { // two tiles at once
+                    const int ti0 = q / tn, tj0 = q - ti0 * tn, ti1 = (q + 3) / tn, tj1 = (q + 3) - ti1 * tn;
+                    const int i0 = ti0 * 16 + c0, ic0 = i0 < nx ? i0 : nx - 1, j0 = tj0 * 16 + c0, jc0 = j0 < nz ? j0 : nz - 1;
+                    const int i1 = ti1 * 16 + c0, ic1 = i1 < nx ? i1 : nx - 1, j1 = tj1 * 16 + c0, jc1 = j1 < nz ? j1 : nz - 1;
+                    mfma_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                    mfma_pair_k4<5>(wl, nx, [&](int, int k) { return Pn[ic0 * pns + k]; }, [&](int k, int) { return S.AB[k * AB_STRIDE + jc0]; },
+                                    [&](int, int k) { return Pn[ic1 * pns + k]; }, [&](int k, int) { return S.AB[k * AB_STRIDE + jc1]; }, acc0, acc1);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int ii0 = ti0 * 16 + r0 + 4 * r, ii1 = ti1 * 16 + r0 + 4 * r;
+                        if (ii0 < nx && j0 < nz) S.PA[ii0 * nz + j0] = acc0[r];
+                        if (ii1 < nx && j1 < nz) S.PA[ii1 * nz + j1] = acc1[r];
+                    }
+                }
+            }
+            for (; q < tx * tn; q += 3) {
                 const int ti = q / tn, tj = q - ti * tn;
                 const int i = ti * 16 + c0, ic = i < nx ? i : nx - 1, j = tj * 16 + c0, jc = j < nz ? j : nz - 1;
                 mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -1205,7 +1249,23 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         for (int qq = 0; qq < MQ; qq++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) m[qq][r] = 0.0;
+        }
+#pragma unroll
+        for (int qp = 0; qp < MQ; qp += 2) { // two tiles at once where the wave has two
+            if (have[qp] && have[qp + 1] && (nx & 3) == 0) {
+                const int i0 = trow[qp] + c0, ic0 = i0 < nz ? i0 : nz - 1, jc0 = colq[qp] < nz ? colq[qp] : nz - 1;
+                const int i1 = trow[qp + 1] + c0, ic1 = i1 < nz ? i1 : nz - 1, jc1 = colq[qp + 1] < nz ? colq[qp + 1] : nz - 1;
+                mfma_d4 acc0 = {gq[qp][0], gq[qp][1], gq[qp][2], gq[qp][3]}, acc1 = {gq[qp + 1][0], gq[qp + 1][1], gq[qp + 1][2], gq[qp + 1][3]};
+                mfma_pair_k4<5>(wl, nx, [&](int, int k) { return S.AB[k * AB_STRIDE + ic0]; }, [&](int k, int) { return S.PA[k * nz + jc0]; },
+                                [&](int, int k) { return S.AB[k * AB_STRIDE + ic1]; }, [&](int k, int) { return S.PA[k * nz + jc1]; }, acc0, acc1);
+#pragma unroll
+                for (int r = 0; r < 4; r++) { m[qp][r] = acc0[r]; m[qp + 1][r] = acc1[r]; }
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < MQ; qq++) {
             if (have[qq]) {
+                if (!(have[qq & ~1] && have[qq | 1] && (nx & 3) == 0)) {
                 const int i = trow[qq] + c0, ic = i < nz ? i : nz - 1, jc = colq[qq] < nz ? colq[qq] : nz - 1;
                 mfma_d4 acc = {gq[qq][0], gq[qq][1], gq[qq][2], gq[qq][3]};
                 if ((nx & 3) == 0)
@@ -1215,6 +1275,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                                                [&](int k, int) { return S.PA[k * nz + jc]; }, acc);
 #pragma unroll
                 for (int r = 0; r < 4; r++) m[qq][r] = acc[r];
+                }
                 // (P_{t+1} in Mf was last read in (1), before the barrier every wave has passed; the state block of M stays
                 // in registers: only the input columns are read by others)
                 if (tcol[qq] + 15 >= nx) {
@@ -1284,14 +1345,15 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         for (int qq = 0; qq < MQ; qq++) {
             if (have[qq] && trow[qq] < nx && tcol[qq] < nx) {
                 const int i = trow[qq] + c0, ixc = i < nx ? i : nx - 1, k = colq[qq], kc = k < nx ? k : nx - 1;
-                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
-                acc = mfma_tile_batched<4>(wl, nu, [&](int, int j) { return Lw[LM_X(nx, nu, ixc, j)]; },
+                // (the products are subtracted from M in pivot order, four pivots per step: the accumulator starts at M)
+                mfma_d4 acc = {m[qq][0], m[qq][1], m[qq][2], m[qq][3]};
+                acc = mfma_tile_batched<4>(wl, nu, [&](int, int j) { return -Lw[LM_X(nx, nu, ixc, j)]; },
                                            [&](int j, int) { return Mf[kc * nz + nx + j]; }, acc);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int row = row0[qq] + 4 * r, col = colq[qq];
                     if (row < nx && col <= row) {
-                        const double v = m[qq][r] - acc[r];
+                        const double v = acc[r];
                         Mf[row * nz + col] = v;
                         Mf[col * nz + row] = v;
                         fac_pr<D>(S)[t * nxs + sym(row, col)] = v;
