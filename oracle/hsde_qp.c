@@ -431,7 +431,7 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 #define POLISH_RHO2 1e7     /* second level, for active sets whose multiplier steps do not settle at the first        */
 #define POLISH_DELTA 1e-10 /* proximal weight of the inactive rows; must stay above eps * rho            */
 #define POLISH_ITERS 5      /* multiplier steps per active set                                            */
-#define POLISH_ROUNDS 6     /* active sets tried per attempt                                              */
+#define POLISH_ROUNDS 10       /* active sets per attempt (round 3: 6 -> 10 together with the rule that every row with a negative multiplier leaves) */
 #ifndef POLISH_ROUNDS_WARM
 #define POLISH_ROUNDS_WARM 3     /* active sets tried when the set is handed down by the parent node */
 #endif
@@ -524,9 +524,14 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
             for (int q = 0; q < p->M; q++) if (k->D[q] >= 1.0) k->D[q] = rho;
             continue;
         }
-        /* Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides, but only those
-         * within a factor two of the worst violation / the most negative multiplier (a missing active row drags
-         * others across their bounds; the next round shows which of them are real). */
+        /* Sign of the multipliers, slack of the inactive rows.  Rows on the wrong side change sides: of the violated
+         * inactive rows only those within a factor two of the worst violation (a missing active row drags others across
+         * their bounds; the next round shows which of them are real); of the active rows EVERY one with a negative
+         * multiplier leaves.  (Until round 3 the multipliers followed the factor-two rule as well: on relaxations with
+         * many weakly active rows -- the random MLD of BASELINE configs[4], binaries outside the cost -- the most negative
+         * multiplier then only halved from round to round and 28 % of the optimal nodes never verified; with this rule and
+         * ten rounds 3 % do not, in fewer factorisations.  Nothing changes on the cart-pole systems: same active sets,
+         * same number of rounds.) */
         double vmax = 0, zmin = 0;
         for (int t = 0; t < T; t++) {
             const double *hh = ht(p, t); int m = mt(p, t), ro = p->roff[t];
@@ -559,7 +564,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
                 int q = ro + r;
                 if (!k->act[q]) continue;
                 if (k->D[q] < 1.0) { if (vmax > es && cw[q] - hh[r] > 0.5 * vmax) { k->D[q] = rho; zk[q] = 0; } }
-                else if (zmin < -ez && zk[q] < 0.5 * zmin) { k->D[q] = POLISH_DELTA; zk[q] = 0; }
+                else if (zmin < -ez && zk[q] < 0.0) { k->D[q] = POLISH_DELTA; zk[q] = 0; }
             }
         }
     }

@@ -44,7 +44,7 @@
 #define HMPC_POLISH_RHO2 1e7 // second level, for active sets whose multiplier steps do not settle at the first
 #define HMPC_POLISH_DELTA 1e-10
 #define HMPC_POLISH_ITERS 5
-#define HMPC_POLISH_ROUNDS 6
+#define HMPC_POLISH_ROUNDS 10 // (round 3: 6 -> 10 together with the rule that every row with a negative multiplier leaves, see below)
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
@@ -2773,9 +2773,12 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // the handed-down set is not near this node's optimum (the node is infeasible, or fixing the
                             // binary moved the solution): dropped after this one factorisation
                         } else if (round + 1 < max_rounds) {
-                            // Rows on the wrong side change sides, but only those within a factor two of the worst
-                            // violation / the most negative multiplier (a missing active row drags others across their
-                            // bounds; the next round shows which are real).
+                            // Rows on the wrong side change sides: of the violated inactive rows only those within a factor
+                            // two of the worst violation (a missing active row drags others across their bounds; the next
+                            // round shows which are real), of the active rows EVERY one with a negative multiplier (with the
+                            // factor-two rule there as well, the most negative multiplier of the random MLD's relaxations only
+                            // halved per round and 28 % of the optimal nodes of BASELINE configs[4] never verified; now 3 %,
+                            // in fewer factorisations; the cart-pole systems take the same rounds as before).
                             act = 1;
                         }
                     } else if (level == 0 && pinf == pinf && round + 1 < max_rounds) {
@@ -2799,7 +2802,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                                 if (d < 1.0) {
                                     if (flip && vmax > es && R.dz(k, rw.e) - rm.h(p, S, k, rw) > 0.5 * vmax) { d = rho; R.dz(k, rw.e) = 0.0; }
                                 } else {
-                                    d = (flip && zmin < -ez && R.dz(k, rw.e) < 0.5 * zmin) ? HMPC_POLISH_DELTA : rho;
+                                    d = (flip && zmin < -ez && R.dz(k, rw.e) < 0.0) ? HMPC_POLISH_DELTA : rho;
                                 }
                                 R.D(k, rw.e) = d;
                                 // next pass: the proximal centre starts at the interior-point iterate again
