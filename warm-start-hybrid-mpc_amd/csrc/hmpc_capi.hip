@@ -362,13 +362,13 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         if (hmpc_lds_bytes(p, 0, big ? 1 : 0) > lds_cu) p.split_lds = 0;
     }
     // streaming form: as many stages per chunk of staged multipliers as LDS has room for
-    for (int r = 4; r >= 1; r--) {
+    for (int r = 2; r >= 1; r--) { // (two stages per chunk hide the slab latency: the barrier of a chunk costs 0.5 % of a solve)
         p.ring = r;
         if (hmpc_lds_bytes(p, 0, 1) <= lds_cu) break;
     }
     if (const char *e = getenv("HMPC_RING")) {
         const int r = atoi(e);
-        if (r >= 1 && r <= 4) p.ring = r;
+        if (r >= 1 && r <= 2) p.ring = r;
     }
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");

@@ -38,7 +38,7 @@ struct DevProb {
     unsigned *check_flag;                      // diagnostic build (HMPC_CHECK): bits raised by failed in-kernel checks; follows work_counter
     double *fac_ws;                            // streaming form: per-workgroup slab for multipliers and cost-to-go
     int fac_stride;                            //   doubles per workgroup
-    int ring;                                  //   stages per chunk the sweeps of a solve stage in LDS (1 .. 4: what fits)
+    int ring;                                  //   stages per chunk the sweeps of a solve stage in LDS (1 or 2: what fits)
     // generic kernel, nz >= 16: the stage rows split into DENSE rows (two or more nonzeros: matrix-core contractions and
     // dense products) and SINGLETON rows (one nonzero -- bounds; they only touch the diagonal of C'DC and one component
     // of a product), staged in LDS when they fit beside the rest (split_lds)

@@ -774,12 +774,15 @@ template <class D> DEV double gram_entry(const DevProb &p, const Lds &S, int t, 
 
 template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, int lane, int t, const ldsd *Pn, int pns);
 template <class D> DEV bool factor_tiles_fits(const DevProb &p);
-template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS);
+template <class D, int MQ> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS);
 
 template <class D> DEV int factor(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
     if constexpr (D::kNT == 4 * WAVE) {
-        if (factor_tiles_fits<D>(p) && !DBG_SKIP(4)) return factor_tiles<D>(p, S, lane FSTAMP_PASS);
+        // (two tiles per tile wave: the 6 lower-triangle tiles of nz <= 48 over three waves.  An instantiation with four --
+        // nz <= 64 -- beside it cost the WHOLE kernel 650 bytes of scratch per lane, measured: 18 GB of HBM traffic per
+        // 1024 nodes of configs[4] against 3; wider stage vectors take the LDS form below.)
+        if (factor_tiles_fits<D>(p) && !DBG_SKIP(4)) return factor_tiles<D, 2>(p, S, lane FSTAMP_PASS);
     }
     FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), ne = D::ne(p);
@@ -1074,7 +1077,7 @@ DEV void mfma_pair_k4(int wl, int K, FA0 a0, FB0 b0, FA1 a1, FB1 b1, mfma_d4 &ac
 template <class D> DEV bool factor_tiles_fits(const DevProb &p)
 {
     const int nz = D::nz(p);
-    return D::kNT == 4 * WAVE && nz >= 16 && nz <= 64 && D::nu(p) <= 16 && p.mreg < 65536;
+    return D::kNT == 4 * WAVE && nz >= 16 && nz <= 48 && D::nu(p) <= 16 && p.mreg < 65536;
 }
 
 // Wave 0 factorises the PANEL, waves 1 .. 3 (the tile waves) own the tiles.  Per stage, backwards in time:
@@ -1091,10 +1094,9 @@ template <class D> DEV bool factor_tiles_fits(const DevProb &p)
 // The LDS form above (dense M in LDS, every entry read, updated and written back per pivot by all threads, one barrier
 // per pivot) took 58 k cycles per stage on configs[4]; with one wave per SIMD the cost of a phase is its instruction
 // count, and that form spent it on index arithmetic and on barriers.
-template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
+template <class D, int MQ> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane FSTAMP_ARGS)
 {
     FSTAMP_DECL;
-    constexpr int MQ = 4;   // tiles per tile wave: nz <= 64 -> 10 lower-triangle tiles over three waves
     constexpr int NUM = 16; // inputs the panel holds per lane
     constexpr int NDS = 8;  // steps of four dense rows whose D a lane keeps in registers (more dense rows: the batched loads)
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
@@ -1110,7 +1112,6 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
     // a tile wave's entries: tile qq -> rows row0[qq] + 4 r, column colq[qq]
     int row0[MQ], colq[MQ], trow[MQ], tcol[MQ];
     bool have[MQ];
-    ldsd *wp[MQ][4], *mp[MQ][4]; // where entry (qq, r) and its mirror image live in Mf
 #pragma unroll
     for (int qq = 0; qq < MQ; qq++) {
         const int q = (wave - 1) + 3 * qq;
@@ -1122,13 +1123,6 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         tcol[qq] = tj * 16;
         row0[qq] = ti * 16 + r0;
         colq[qq] = tj * 16 + c0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = row0[qq] + 4 * r, col = colq[qq];
-            const bool ok = have[qq] && row < nz && col < nz;
-            wp[qq][r] = ok ? Mf + row * nz + col : dump;
-            mp[qq][r] = ok ? Mf + col * nz + row : dump;
-        }
     }
     for (int e = lane; e < nx * nx; e += D::kNT) {
         const int i = e / nx, j = e - i * nx;
@@ -1195,9 +1189,9 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
             }
         }
     };
-    gram(T - 1);
     int bad = 0;
-    for (int t = T - 1; t >= 0; t--) {
+    for (int t = T; t >= 0; t--) {
+        const bool stage = t < T; // (t == T: the prologue -- only the Gram part of the last stage, by the code of (3))
         const ldsd *Pn = t == T - 1 ? S.PT : Mf; // P_{t+1}: the terminal Hessian, or the block the previous stage left
         const int pns = t == T - 1 ? nx : nz;
         const ldsi *fx = S.fix + t * nub;
@@ -1206,7 +1200,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         if constexpr (D::kBig) Lw = S.Lw;
         else Lw = S.Lm + t * lms;
         // (1) PA = P_{t+1} [A B]  (nx x nz)
-        if (tilew) {
+        if (tilew && stage) {
             int q = wave - 1;
             if ((nx & 3) == 0) {
                 for (; q + 3 < tx * tn; q += 6) { // two tiles at once
@@ -1240,8 +1234,10 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                 }
             }
         }
-        for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
-        lds_barrier();
+        if (stage) {
+            for (int e = lane; e < lms; e += D::kNT) Lw[e] = 0.0;
+            lds_barrier();
+        }
         FSTAMP(0);
         // (2) the tiles of M, in registers; their input columns to LDS
         double m[MQ][4];
@@ -1252,7 +1248,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         }
 #pragma unroll
         for (int qp = 0; qp < MQ; qp += 2) { // two tiles at once where the wave has two
-            if (have[qp] && have[qp + 1] && (nx & 3) == 0) {
+            if (stage && have[qp] && have[qp + 1] && (nx & 3) == 0) {
                 const int i0 = trow[qp] + c0, ic0 = i0 < nz ? i0 : nz - 1, jc0 = colq[qp] < nz ? colq[qp] : nz - 1;
                 const int i1 = trow[qp + 1] + c0, ic1 = i1 < nz ? i1 : nz - 1, jc1 = colq[qp + 1] < nz ? colq[qp + 1] : nz - 1;
                 mfma_d4 acc0 = {gq[qp][0], gq[qp][1], gq[qp][2], gq[qp][3]}, acc1 = {gq[qp + 1][0], gq[qp + 1][1], gq[qp + 1][2], gq[qp + 1][3]};
@@ -1264,7 +1260,7 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
         }
 #pragma unroll
         for (int qq = 0; qq < MQ; qq++) {
-            if (have[qq]) {
+            if (stage && have[qq]) {
                 if (!(have[qq & ~1] && have[qq | 1] && (nx & 3) == 0)) {
                 const int i = trow[qq] + c0, ic = i < nz ? i : nz - 1, jc = colq[qq] < nz ? colq[qq] : nz - 1;
                 mfma_d4 acc = {gq[qq][0], gq[qq][1], gq[qq][2], gq[qq][3]};
@@ -1278,20 +1274,30 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                 }
                 // (P_{t+1} in Mf was last read in (1), before the barrier every wave has passed; the state block of M stays
                 // in registers: only the input columns are read by others)
+                // (entries of a tile that overhang the matrix go to a dump slot: no predicate on the stores)
                 if (tcol[qq] + 15 >= nx) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) *wp[qq][r] = m[qq][r];
+                    for (int r = 0; r < 4; r++) {
+                        const int row = row0[qq] + 4 * r, col = colq[qq];
+                        ldsd *w = (row < nz && col < nz) ? Mf + row * nz + col : dump;
+                        *w = m[qq][r];
+                    }
                 }
                 if (trow[qq] != tcol[qq] && trow[qq] + 15 >= nx) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) *mp[qq][r] = m[qq][r];
+                    for (int r = 0; r < 4; r++) {
+                        const int row = row0[qq] + 4 * r, col = colq[qq];
+                        ldsd *w = (row < nz && col < nz) ? Mf + col * nz + row : dump;
+                        *w = m[qq][r];
+                    }
                 }
             }
         }
-        lds_barrier();
+        if (stage) lds_barrier();
         FSTAMP(1);
         // (3) wave 0: mb and the panel; tile waves: the Gram part of the next stage
         if (!tilew) {
+          if (stage) {
             const int i = lane, ic = i < nz ? i : 0, b0 = nx + nuc;
             const int fxv = i < nub ? fx[i < nub ? i : 0] : -1;
             const unsigned long long fm1 = __ballot(fxv >= 0), fone = __ballot(fxv == 1);
@@ -1312,7 +1318,8 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
             }
             // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
             // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
-            int nuo = nu;
+            int nuo = __builtin_amdgcn_readfirstlane(nu);
+            fixmask = __builtin_amdgcn_readfirstlane(fixmask);
 #pragma unroll
             for (int j = 0; j < NUM; j++) {
                 asm volatile("" : "+s"(nuo), "+s"(fixmask));
@@ -1335,9 +1342,11 @@ template <class D> DEV int factor_tiles(const DevProb &p, const Lds &S, int lane
                 }
             }
             if (bad && lane == 0) S.flag[0] = 1; // (wave 0 alone sees the pivots)
+          }
         } else if (t > 0) {
             gram(t - 1);
         }
+        if (!stage) continue;
         lds_barrier();
         FSTAMP(3);
         // (4) state block on the matrix cores, by the waves that hold its tiles
@@ -1770,7 +1779,7 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
         // likewise.  Wave 0 -- the only wave at work, its instruction count IS the time of a solve -- then runs fixed
         // four-wide steps with no bound tests, clamps or selects: a term past the end multiplies a zero (measured on
         // configs[4]: 7 k cycles per stage and sweep with tested / clamped loads, [see DESIGN 4.2] in this form).
-        constexpr int RMAX = 4, STG = 8; // stages per chunk; doubles per fetching thread and stage: lms <= 8 * fetchers (checked by the caller)
+        constexpr int RMAX = 2, STG = 8; // stages per chunk (DevProb::ring <= RMAX); doubles per fetching thread and stage: lms <= 8 * fetchers (checked by the caller)
         const int R = p.ring, nch = (T + R - 1) / R;
         const int fetchers = D::kNT > WAVE ? D::kNT - WAVE : D::kNT, fid = D::kNT > WAVE ? lane - WAVE : lane;
         const bool helper = fid >= 0;
