@@ -59,4 +59,25 @@ mld, objective, x0 = random_mld(nx=6, nuc=2, nub=3, seed=3)
 ctrl = HybridModelPredictiveController(mld, 8, objective, None, backend=_NoBackend())
 fix = random_prefix_frontier(8, 3, 128, p_one=0.3)
 run('random MLD nx=6', HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=16), x0, fix, 8, 6)
+# BASELINE configs[4]: the streaming form with the split stage rows, the panel factorisation and the padded sweeps
+# (a dive frontier: mostly optimal nodes; the x deviation is of POLISHED records only -- see test_gpu_parity.py on the others)
+mld, objective, x0 = random_mld()
+ctrl = HybridModelPredictiveController(mld, 30, objective, None, backend=_NoBackend())
+hip4, orc4 = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=16)
+Cj = np.array([mld.F[52 + 4 * j] for j in range(8)])
+leaf = np.full((1, 240), -1, np.int8)
+for t in range(30):
+    r = orc4.solve_batch(x0, leaf)
+    leaf[0, t * 8:(t + 1) * 8] = (r['primal'][0][:31 * 20].reshape(31, 20)[t] @ Cj.T >= 0)
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from bench import dive_frontier
+f4 = dive_frontier(leaf[0], 320, 0)
+a, b = hip4.solve_batch(x0, f4), orc4.solve_batch(x0, f4)
+both = (a['status'] == 0) & (a['polished'] > 0) & (b['polished'] > 0)
+dev = np.abs(a['primal'][both][:, :31 * 20] - b['primal'][both][:, :31 * 20]).max()
+nan = int(np.isnan(a['primal'][a['status'] == 0]).sum() + np.isnan(a['dual']).sum())
+good = np.array_equal(a['status'], b['status']) and dev < 1e-5 and nan == 0
+bad += not good
+print('ok  ' if good else 'FAIL', 'random MLD nx=20 nu=6+8 N=30 (streaming form) nodes', len(f4), 'optimal', int((a['status'] == 0).sum()), 'polished on both sides', int(both.sum()),
+      'x dev %.1e' % dev, 'NaNs', nan, flush=True)
 print('CHECK BUILD:', 'all instantiations clean' if bad == 0 else '%d FAILURES' % bad)
