@@ -431,7 +431,8 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 #define POLISH_RHO2 1e7     /* second level, for active sets whose multiplier steps do not settle at the first        */
 #define POLISH_DELTA 1e-10 /* proximal weight of the inactive rows; must stay above eps * rho            */
 #define POLISH_ITERS 5      /* multiplier steps per active set                                            */
-#define POLISH_ROUNDS 10       /* active sets per attempt (round 3: 6 -> 10 together with the rule that every row with a negative multiplier leaves) */
+#define POLISH_ROUNDS 6        /* active sets tried per attempt ...                                        */
+#define POLISH_ROUNDS_LAST 10  /* ... and by the last attempt, on the iterate the solve would return (round 3, with the rule that every row with a negative multiplier leaves) */
 #ifndef POLISH_ROUNDS_WARM
 #define POLISH_ROUNDS_WARM 3     /* active sets tried when the set is handed down by the parent node */
 #endif
@@ -443,7 +444,7 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 /* zwarm (optional, M entries, solver units, tau = 1): multipliers handed down by the parent node -- the active set is
  * read from them (z > 0: the parent's record is a polished vertex, exactly complementary) instead of from the iterate,
  * and k->w holds the parent's primal point with the child's prescribed components written over it. */
-static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm)
+static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm, int last)
 {
     int nz = p->nz, T = p->T;
     double rho = POLISH_RHO;
@@ -477,7 +478,8 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
     (void)zinf;
     /* (a hand-down that does not verify on the parent's set or after one exchange of rows is dropped: the child's
      * optimum is elsewhere -- typically the child is infeasible -- and every further round costs an iteration's worth) */
-    const int max_rounds = zwarm ? POLISH_ROUNDS_WARM : POLISH_ROUNDS;
+    /* (last: the attempt on the iterate the solve would return -- the one that gets the longer sequence of active sets) */
+    const int max_rounds = zwarm ? POLISH_ROUNDS_WARM : last ? POLISH_ROUNDS_LAST : POLISH_ROUNDS;
     for (int round = 0; round < max_rounds; round++) {
         if (factor(p, k, fix) != 0) { return 0; }
         memcpy(cw, cw0, sizeof(double) * p->M); /* the proximal centre starts at the interior-point iterate */
@@ -530,7 +532,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
          * multiplier leaves.  (Until round 3 the multipliers followed the factor-two rule as well: on relaxations with
          * many weakly active rows -- the random MLD of BASELINE configs[4], binaries outside the cost -- the most negative
          * multiplier then only halved from round to round and 28 % of the optimal nodes never verified; with this rule and
-         * ten rounds 3 % do not, in fewer factorisations.  Nothing changes on the cart-pole systems: same active sets,
+         * ten rounds in the last attempt 3 % do not, in fewer factorisations.  Nothing changes on the cart-pole systems: same active sets,
          * same number of rounds.) */
         double vmax = 0, zmin = 0;
         for (int t = 0; t < T; t++) {
@@ -633,7 +635,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             }
         }
         for (int i = 0; i < (T + 1) * nx; i++) if (fabs(wdual[i]) * p->cs > zinf0) zinf0 = fabs(wdual[i]) * p->cs;
-        if (bmove <= POLISH_WARM_BMOVE && winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
+        if (bmove <= POLISH_WARM_BMOVE && winf0 == winf0 && zinf0 == zinf0 && polish(p, k, x0, fix, 1.0, winf0, zinf0, 0.0, zw, 0)) { status = ST_OPTIMAL; polished = POLISH_ATTEMPTS + 2; it = 0; tau = 1.0; goto output; }
         if (attempt_only) return -1; /* (the caller goes on with the regular sequence of solves) */
         memset(k->w, 0, sizeof(double) * n);
         for (int i = 0; i < nx; i++) k->w[i] = x0[i] * tau;
@@ -714,7 +716,7 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
             const int ready = do_polish && (npol < POLISH_ATTEMPTS ? (acceptable || exhausted || (status != ST_OPTIMAL && rcinf / tau <= ptol * (1 + winf + x0inf) &&
                                                                         rdinf / tau <= ptol * (1 + zinf) && gap <= gptol))
                                                                    : (npol == POLISH_ATTEMPTS && final_exit));
-            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha, NULL)) { status = ST_OPTIMAL; polished = npol; break; } }
+            if (ready) { npol++; if (polish(p, k, x0, fix, tau, winf, zinf, last_alpha, NULL, npol > POLISH_ATTEMPTS)) { status = ST_OPTIMAL; polished = npol; break; } }
             if (acceptable) {
                 status = ST_OPTIMAL;
                 if ((gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tol * (1 + zinf)) || extra_done >= 3 || it == max_iter) break;

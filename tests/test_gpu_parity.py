@@ -77,8 +77,9 @@ def _dense_check(ctrl, T, x0, fix, rec, sample=64, seed=0):
     statement of the node QP, no code shared with oracle or kernel) -- a seeded sample per call, states to 1e-7."""
     from dense_qp import dense_qp, active_set_primal
     key = id(ctrl)
-    if key not in _DENSE:
-        _DENSE[key] = dense_qp(ctrl)
+    if getattr(ctrl, '_dense_qp_of_the_parity_tests', None) is None:   # (kept on the controller: id() of a collected one is reused)
+        ctrl._dense_qp_of_the_parity_tests = dense_qp(ctrl)
+    _DENSE[key] = ctrl._dense_qp_of_the_parity_tests
     opt = np.flatnonzero((rec['status'] == 0) & (rec['polished'] > 0))
     if opt.size > sample:
         opt = np.random.RandomState(seed).choice(opt, sample, replace=False)

@@ -44,7 +44,8 @@
 #define HMPC_POLISH_RHO2 1e7 // second level, for active sets whose multiplier steps do not settle at the first
 #define HMPC_POLISH_DELTA 1e-10
 #define HMPC_POLISH_ITERS 5
-#define HMPC_POLISH_ROUNDS 10 // (round 3: 6 -> 10 together with the rule that every row with a negative multiplier leaves, see below)
+#define HMPC_POLISH_ROUNDS 6
+#define HMPC_POLISH_ROUNDS_LAST 10 // the last attempt, on the iterate the solve would return (round 3, with the rule that every row with a negative multiplier leaves)
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
@@ -2726,7 +2727,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (mode != 0) {
             // ---------------- polish: multiplier step, verification, next pass ----------------
             int outcome = 0; // 0 give up, 1 verified, 2 next pass
-            const int max_rounds = (WARM && warm_try) ? HMPC_POLISH_ROUNDS_WARM : HMPC_POLISH_ROUNDS;
+            const int max_rounds = (WARM && warm_try) ? HMPC_POLISH_ROUNDS_WARM : attempts > HMPC_POLISH_ATTEMPTS ? HMPC_POLISH_ROUNDS_LAST : HMPC_POLISH_ROUNDS;
             if (mode != 3) {
                 double pinf = 0, pmove = 0;
                 ROWS_BEGIN(k, rw)
@@ -2786,8 +2787,8 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // two of the worst violation (a missing active row drags others across their bounds; the next
                             // round shows which are real), of the active rows EVERY one with a negative multiplier (with the
                             // factor-two rule there as well, the most negative multiplier of the random MLD's relaxations only
-                            // halved per round and 28 % of the optimal nodes of BASELINE configs[4] never verified; now 3 %,
-                            // in fewer factorisations; the cart-pole systems take the same rounds as before).
+                            // halved per round and 28 % of the optimal nodes of BASELINE configs[4] never verified; now -- with ten
+                            // rounds in the last attempt -- 3 %, in fewer factorisations; the cart-pole systems take the same rounds as before).
                             act = 1;
                         }
                     } else if (level == 0 && pinf == pinf && round + 1 < max_rounds) {
