@@ -105,7 +105,13 @@ typedef struct hmpc_result {
     int32_t *status;  /* B                                                                    */
     int32_t *iters;   /* B : interior-point iterations spent on the node (low 16 bits);       */
                       /*     bit 16 (HMPC_ITERS_POLISHED): the record is the polished vertex    */
-                      /*     solution (exactly complementary), not the interior-point iterate;  */
+                      /*     solution (exactly complementary), not the interior-point iterate.  */
+                      /*     An OPTIMAL record WITHOUT the bit is the iterate that met the      */
+                      /*     stopping test (gap <= 1e-8, or 1e-6 at the floor of the barrier    */
+                      /*     parameter): optimal to that tolerance and carrying its own KKT     */
+                      /*     certificate, but reproducible across arithmetic orders only to     */
+                      /*     ~1e-4 in the trajectory.  Every optimal node of the cart-pole      */
+                      /*     systems polishes; 1.5 % of BASELINE configs[4]'s do not;           */
                       /*     bit 17 (HMPC_ITERS_WEAK): infeasible by about the accuracy of the  */
                       /*     arithmetic -- the embedding's tau collapsed, the node has no point */
                       /*     feasible to tolerance and is pruned, but its ray misses the proof  */
