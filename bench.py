@@ -244,7 +244,7 @@ def other_configs(dev):
     r, _ = _device_rate(c4.qp, x0, f, dev, reps=3, warm=1)
     r['algorithmic_bytes_per_qp'] = c4.layout.bytes_per_qp()
     r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
-    r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: lists and Riccati factor in global memory)'
+    r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: factor in a global slab; panel elimination on wave 0, tiles on the matrix cores)'
     r['frontier'] = '4096 distinct nodes: prefixes of a dive to a feasible leaf, every other one with one binary flipped (random prefixes of this generator are all infeasible)'
     out['random_mld_nx20_nu14_N30_dive_frontier_4096'] = r
     return out

@@ -51,3 +51,8 @@ t0 = time.perf_counter()
 r = hip.solve_batch(x0, f[:B])
 dt = time.perf_counter() - t0
 print('B %d: %.1f ms, %.0f QP/s; launch %s; statuses %s' % (B, 1e3 * dt, B / dt, hip.launch_info(), np.unique(r['status'], return_counts=True)))
+if os.environ.get('DBG_SWAP'):   # phase stamps of another node than the root: put it first
+    k = int(os.environ['DBG_SWAP'])
+    g = f[:B].copy(); g[[0, k]] = g[[k, 0]]
+    r2 = hip.solve_batch(x0, g)
+    print('node %d first: iterations %d polished %d status %d' % (k, r2['iters'][0], r2['polished'][0], r2['status'][0]))

@@ -90,7 +90,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
     d += T * nu + (big ? 0 : T * lms + (T + 1) * nxs);                    // dinv ; Lm Pr (global slab if big)
     d += n + 2 * T * nx + n + (T + 1) * nx;                               // rd rdyn edyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
-    d += nx + nz + 40;                                                    // q mv red
+    d += (nx + 3) / 4 * 4 + nz + 40;                                      // q (padded to four) mv red
     d += nx;                                                              // x0
     if (big) {                                                            // AB padded, P, PT
         const size_t nur = (nu + 3) / 4 * 4, nup = (nu + 1 + 3) / 4 * 4, lrows = nz + 1 > nx + nur ? nz + 1 : nx + nur;

@@ -404,14 +404,18 @@ template <class D> DEV double crow_dot(const DevProb &p, const Lds &S, int lr, c
             const int ri = S.rinfo[lr];
             if (ri >= 0) return S.sval[lr] * v[ri]; // singleton row
             const ldsd *c = S.Cdn + (-ri - 1) * nz;
-            double a0 = 0, a1 = 0;
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
             int j = 0;
-            for (; j + 2 <= nz; j += 2) {
-                a0 += c[j] * v[j];
-                a1 += c[j + 1] * v[j + 1];
+            for (; j + 4 <= nz; j += 4) { // (eight loads in flight per trip: the loop's instructions are the time of a row phase)
+                const double c0 = c[j], c1 = c[j + 1], c2 = c[j + 2], c3 = c[j + 3];
+                const double v0 = v[j], v1 = v[j + 1], v2 = v[j + 2], v3 = v[j + 3];
+                a0 += c0 * v0;
+                a1 += c1 * v1;
+                a2 += c2 * v2;
+                a3 += c3 * v3;
             }
-            if (j < nz) a0 += c[j] * v[j];
-            return a0 + a1;
+            for (; j < nz; j++) a0 += c[j] * v[j];
+            return (a0 + a1) + (a2 + a3);
         }
     }
     if (lr < p.mreg) return row_dot(stage_lists<D>(S), lr, v);
@@ -990,16 +994,12 @@ template <class D> DEV void stage_matrix_mfma(const DevProb &p, const Lds &S, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// The factorisation of the run-time-sized kernel with four waves per node and 16 <= nz <= 64 (BASELINE configs[4]): the
-// stage matrix never leaves the registers it is computed in.  The lower-triangle 16 x 16 tiles of
+// The factorisation of the run-time-sized kernel with four waves per node, 16 <= nz <= 48 and nu <= 16 (BASELINE
+// configs[4]): factor_tiles below.  The 16 x 16 tiles of
 //   M = P + C' D C + [A B]' P_{t+1} [A B]
-// are dealt to the waves (tile q to wave q mod 4, at most three per wave); a lane holds the four entries of a tile the
-// matrix-core instruction returns to it (rows (l >> 4) + 4 r of column l & 15) and keeps them through the elimination:
-// per pivot the owners of the pivot column (lower triangle: column pj below the diagonal, row pj left of it) publish it
-// in LDS, ONE LDS-only barrier, and every lane updates its own entries from the five values it needs per tile.  The
-// operands of the contractions are fetched in batches (all loads of five steps in flight before the first product).
-// The LDS form above (dense M in LDS, every entry read, updated and written back per pivot, index arithmetic per
-// entry) took 58 k cycles per stage on configs[4], this one [measured below in DESIGN 4.2].
+// stay in the registers the matrix-core instruction returns them in (a lane: rows (l >> 4) + 4 r of column l & 15 of its
+// tiles); their operands are fetched in batches -- all loads of a batch in flight before its first product -- and two tiles
+// are interleaved where a wave has two.  First the helpers the tiles are computed with.
 // What the stage leaves behind is what the LDS form leaves: multipliers, reciprocal pivots, P_t, mb.
 // ---------------------------------------------------------------------------------------------
 template <int NB, class FA, class FB> DEV mfma_d4 mfma_tile_batched(int wl, int K, FA a, FB b, mfma_d4 acc)
@@ -1779,7 +1779,7 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
         // zero beyond its entries, and zero rows follow the last component; [A B] carries a zero column and zero rows
         // likewise.  Wave 0 -- the only wave at work, its instruction count IS the time of a solve -- then runs fixed
         // four-wide steps with no bound tests, clamps or selects: a term past the end multiplies a zero (measured on
-        // configs[4]: 7 k cycles per stage and sweep with tested / clamped loads, [see DESIGN 4.2] in this form).
+        // configs[4]: 7 k cycles per stage and sweep with tested / clamped loads, 3.3 k in this form).
         constexpr int RMAX = 2, STG = 8; // stages per chunk (DevProb::ring <= RMAX); doubles per fetching thread and stage: lms <= 8 * fetchers (checked by the caller)
         const int R = p.ring, nch = (T + R - 1) / R;
         const int fetchers = D::kNT > WAVE ? D::kNT - WAVE : D::kNT, fid = D::kNT > WAVE ? lane - WAVE : lane;
@@ -1846,14 +1846,18 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
             const int j = lane, jc = j < nz ? j : nz; // (column nz of [A B] and row nz of the block are zero)
             const double qv = lane < nx ? pvr + S.pv[t * nx + lane] : 0.0;
             double v0 = j < nz ? S.g[t * nz + (j < nz ? j : 0)] : 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+            // (q goes through LDS -- one write, then uniform reads that every lane shares -- instead of two v_readlane and a
+            // wait state per term; the chain of the substitution below cannot: its terms depend on each other)
+            if (lane < nxr) S.q[lane] = qv; // (lanes nx .. nxr-1: zero)
             const ldsd *ab = S.AB + jc;
             for (int l = 0; l < nxr; l += 4) { // (rows nx .. nxr-1 of [A B] are zero rows)
                 const double c0 = ab[0], c1 = ab[abst], c2 = ab[2 * abst], c3 = ab[3 * abst];
+                const double q0 = S.q[l], q1 = S.q[l + 1], q2 = S.q[l + 2], q3 = S.q[l + 3];
                 ab += 4 * abst;
-                v0 += c0 * bcast(qv, l);
-                v1 += c1 * bcast(qv, l + 1);
-                v2 += c2 * bcast(qv, l + 2);
-                v3 += c3 * bcast(qv, l + 3);
+                v0 += c0 * q0;
+                v1 += c1 * q1;
+                v2 += c2 * q2;
+                v3 += c3 * q3;
             }
             double v = (v0 + v1) + (v2 + v3);
             if (j >= nx + nuc && j < nz) {
@@ -1881,11 +1885,12 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
             double cur = j < nu ? S.dinv[t * nu + (j < nu ? j : 0)] * dw[t * nz + nx + (j < nu ? j : 0)] : 0.0;
             double xn = (csrc && j < nx) ? cs * csrc[t * nx + (j < nx ? j : 0)] : 0.0;
             const ldsd *lc = Lp + ju, *ar = S.AB + jr * abst;
-            for (int l = 0; l < nxr; l += 4) { // (lanes nx .. of x are zero: what a term past nx multiplies does not matter)
+            if (lane < nxr) S.q[lane] = xr; // (x through LDS, as q in the backward sweep; lanes nx .. hold zero)
+            for (int l = 0; l < nxr; l += 4) { // (entries nx .. of x are zero: what a term past nx multiplies does not matter)
                 const double a0 = ar[l], a1 = ar[l + 1], a2 = ar[l + 2], a3 = ar[l + 3];
                 const double c0 = lc[0], c1 = lc[nup], c2 = lc[2 * nup], c3 = lc[3 * nup];
                 lc += 4 * nup;
-                const double x0 = bcast(xr, l), x1 = bcast(xr, l + 1), x2 = bcast(xr, l + 2), x3 = bcast(xr, l + 3);
+                const double x0 = S.q[l], x1 = S.q[l + 1], x2 = S.q[l + 2], x3 = S.q[l + 3];
                 cur += c0 * x0; xn += a0 * x0;
                 cur += c1 * x1; xn += a1 * x1;
                 cur += c2 * x2; xn += a2 * x2;
@@ -3185,10 +3190,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         const int dir2 = n + (T + 1) * nx + T * nub, fscr = nz * nz + (D::kKC > 0 ? nz * nz : nx * nz);
         S.w2 = take(dir2 > fscr ? dir2 : fscr); S.lam2 = S.w2 + n; S.nuf2 = S.lam2 + (T + 1) * nx;
         S.Mm = S.w2; S.PA = S.Mm + nz * nz;
-        S.q = take(nx); S.mv = take(nz); S.red = take(40);
+        S.q = take((nx + 3) / 4 * 4); S.mv = take(nz); S.red = take(40);
         S.x0 = take(nx);
         // streaming form: [A B] padded (zero column nz, zero rows nx ..), stage blocks of multipliers padded to
-        // lrows x nup (zero beyond a row's entries) -- must mirror hmpc_pad_dims() in hmpc_device.h
+        // lrows x nup (zero beyond a row's entries) -- must mirror hmpc_lds_bytes() in hmpc_device.h
         S.abst = nz; S.nup = 0; S.lrows = 0;
         int abrows = nx;
         if constexpr (D::kBig) {
