@@ -111,7 +111,7 @@ typedef struct hmpc_result {
                       /*     parameter): optimal to that tolerance and carrying its own KKT     */
                       /*     certificate, but reproducible across arithmetic orders only to     */
                       /*     ~1e-4 in the trajectory.  Every optimal node of the cart-pole      */
-                      /*     systems polishes; 1.5 % of BASELINE configs[4]'s do not;           */
+                      /*     systems polishes; 2 % of BASELINE configs[4]'s do not;              */
                       /*     bit 17 (HMPC_ITERS_WEAK): infeasible by about the accuracy of the  */
                       /*     arithmetic -- the embedding's tau collapsed, the node has no point */
                       /*     feasible to tolerance and is pruned, but its ray misses the proof  */
