@@ -108,3 +108,15 @@ def test_headline_kernel_keeps_its_register_budget(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
     assert scratch and max(scratch) <= 128, scratch
+    # The streaming form of the generic kernel (BASELINE configs[4]) must not spill at all: a second instantiation of its
+    # tile code once cost the whole kernel 650 B of scratch per lane -- 134 KB per workgroup pushed through an L2 the
+    # factor slabs already overflow.
+    src.write_text('#define HMPC_KERNEL_ONLY\n#include "hmpc_device.h"\n#include "hmpc_kernel.hip"\n'
+                   'template __global__ void hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>(const DevProb, const double *, int, const int8_t *, int, '
+                   'const DevOut, double *, double *, const int32_t *, const DevWarm);\n')
+    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-Wno-pass-failed',
+                        '-I', os.path.join(ROOT, 'include'), '-I', csrc, '-c', str(src), '-o', str(tmp_path / 'probe.o'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+    assert scratch and max(scratch) == 0, scratch
