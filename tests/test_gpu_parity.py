@@ -411,6 +411,42 @@ def test_streaming_kernel_baseline_config4():
         HipBatchedQP(huge.problem_data())
 
 
+@pytest.mark.parametrize('nx,nuc,nub,T,seed', [(13, 3, 5, 12, 1), (8, 8, 8, 10, 3), (32, 10, 8, 6, 10), (16, 4, 0, 8, 8)])
+def test_streaming_kernel_other_shapes(monkeypatch, nx, nuc, nub, T, seed):
+    # the streaming form forced onto other random MLDs: a state count that is no multiple of four (padded blocks, partial
+    # batches of the matrix-core tiles), nu = 16 (the limit of the panel form), nz = 50 with nu = 18 (the LDS form of the
+    # factorisation), no binaries at all -- tests/gpu_streaming_shapes.py runs twelve of them on the bounds-checked build
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    monkeypatch.setenv('HMPC_FORCE_BIG', '1')
+    hip = HipBatchedQP(ctrl.problem_data())
+    monkeypatch.delenv('HMPC_FORCE_BIG')
+    orc = OracleBatchedQP(ctrl.problem_data(), threads=8)
+    count = 48
+    fix = np.full((count, T * nub), -1, np.int8)
+    if nub:
+        Cj = np.array([mld.F[2 * nx + 2 * nuc + 4 * j] for j in range(nub)])
+        leaf = np.full((1, T * nub), -1, np.int8)
+        for t in range(T):
+            r = orc.solve_batch(x0, leaf)
+            assert r['status'][0] == 0
+            leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+        rng = np.random.default_rng(seed)
+        for k in range(1, count):
+            d = int(rng.integers(1, T * nub + 1))
+            fix[k, :d] = leaf[0, :d]
+            if k % 2 == 0:
+                j = int(rng.integers(0, d))
+                fix[k, j] = 1 - fix[k, j]
+    a, b = hip.solve_batch(x0, fix), orc.solve_batch(x0, fix)
+    assert hip.launch_info()[0] >= 1
+    _compare(ctrl, a, b, T, fix, min_polished=0.6)
+    assert (a['status'] == 0).sum() >= 1
+
+
 def test_streaming_kernel_forced_on_cart_pole(monkeypatch):
     # the same streaming code path on the reference's system, against the oracle
     monkeypatch.setenv('HMPC_FORCE_BIG', '1')
