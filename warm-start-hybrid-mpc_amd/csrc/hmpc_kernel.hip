@@ -1310,37 +1310,50 @@ template <class D, int MQ> DEV int factor_tiles(const DevProb &p, const Lds &S, 
                 S.g[t * nz + i] = g;
             }
             const bool rowfixed = i >= nx && i < nz && ((fixmask >> (i - nx)) & 1u);
-            double a[NUM];
+            // NC: columns of the panel held per lane.  A stage whose binaries are ALL fixed by the node -- the upper stages
+            // of every deep node of a search -- only has its continuous inputs to eliminate: the narrow form (eight columns)
+            // does a quarter of the broadcast-and-update steps of the full one.
+            auto panel = [&](auto nc_, int ncols) {
+                constexpr int NC = decltype(nc_)::value;
+                double a[NC];
 #pragma unroll
-            for (int k = 0; k < NUM; k++) {
-                const double x = Mf[ic * nz + nx + (k < nu ? k : 0)];
-                const bool pres = rowfixed || ((fixmask >> k) & 1u); // prescribed component: identity row / column
-                a[k] = (k < nu && i < nz) ? (pres ? (i == nx + k ? 1.0 : 0.0) : x) : 0.0;
-            }
-            // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
-            // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
-            int nuo = __builtin_amdgcn_readfirstlane(nu);
-            fixmask = __builtin_amdgcn_readfirstlane(fixmask);
+                for (int k = 0; k < NC; k++) {
+                    const double x = Mf[ic * nz + nx + (k < ncols ? k : 0)];
+                    const bool pres = rowfixed || ((fixmask >> k) & 1u); // prescribed component: identity row / column
+                    a[k] = (k < ncols && i < nz) ? (pres ? (i == nx + k ? 1.0 : 0.0) : x) : 0.0;
+                }
+                // (the bounds and the mask are made opaque per pivot: tested where they are used, two scalar instructions,
+                // instead of sixteen lane masks computed ahead of the loop, spilled, and fetched back at every use)
+                int nuo = __builtin_amdgcn_readfirstlane(ncols);
+                unsigned fmask = __builtin_amdgcn_readfirstlane(fixmask);
 #pragma unroll
-            for (int j = 0; j < NUM; j++) {
-                asm volatile("" : "+s"(nuo), "+s"(fixmask));
-                if (j < nuo) {
-                    if (i < nz) Mf[i * nz + nx + j] = a[j]; // the column as it stands: second operand of the state block's product
-                    if ((fixmask >> j) & 1u) { // decoupled unit pivot: the solves skip it as well
-                        if (lane == 0) S.dinv[t * nu + j] = 1.0;
-                    } else {
-                        const double d = bcast(a[j], nx + j);
-                        if (!(d > 0.0)) bad = 1;
-                        double rinv = __builtin_amdgcn_rcp(d);
-                        rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
-                        const bool trailing = i < nx || (i > nx + j && i < nz);
-                        const double mval = a[j] * rinv, meff = trailing ? mval : 0.0;
+                for (int j = 0; j < NC; j++) {
+                    asm volatile("" : "+s"(nuo), "+s"(fmask));
+                    if (j < nuo) {
+                        if (i < nz) Mf[i * nz + nx + j] = a[j]; // the column as it stands: second operand of the state block's product
+                        if ((fmask >> j) & 1u) { // decoupled unit pivot: the solves skip it as well
+                            if (lane == 0) S.dinv[t * nu + j] = 1.0;
+                        } else {
+                            const double d = bcast(a[j], nx + j);
+                            if (!(d > 0.0)) bad = 1;
+                            double rinv = __builtin_amdgcn_rcp(d);
+                            rinv = rinv * (2.0 - d * rinv); // one Newton step on the hardware reciprocal
+                            const bool trailing = i < nx || (i > nx + j && i < nz);
+                            const double mval = a[j] * rinv, meff = trailing ? mval : 0.0;
 #pragma unroll
-                        for (int k = j + 1; k < NUM; k++) a[k] -= meff * bcast(a[k], nx + j); // (columns nu .. are zero and stay zero)
-                        if (trailing) Lw[i < nx ? LM_X(nx, nu, i, j) : LM_U(nx, nu, i - nx, j)] = mval;
-                        if (lane == 0) S.dinv[t * nu + j] = rinv;
+                            for (int k = j + 1; k < NC; k++) a[k] -= meff * bcast(a[k], nx + j); // (columns past the last are zero and stay zero)
+                            if (trailing) Lw[i < nx ? LM_X(nx, nu, i, j) : LM_U(nx, nu, i - nx, j)] = mval;
+                            if (lane == 0) S.dinv[t * nu + j] = rinv;
+                        }
                     }
                 }
+            };
+            constexpr int NUMC = 8;
+            if (nub > 0 && nuc <= NUMC && __popcll(fm1) == nub) {
+                panel(std::integral_constant<int, NUMC>(), nuc);
+                if (lane < nub) S.dinv[t * nu + nuc + lane] = 1.0; // (the binaries: unit pivots, their multipliers stay zero)
+            } else {
+                panel(std::integral_constant<int, NUM>(), nu);
             }
             if (bad && lane == 0) S.flag[0] = 1; // (wave 0 alone sees the pivots)
           }
@@ -1865,8 +1878,11 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
                 if (f >= 0) v = (useb && f == 1) ? -1.0 : 0.0;
             }
             // forward substitution: the factorisation's row operations applied to the vector
+            // (a stage whose binaries are all fixed: their pivots were skipped, their multipliers are zero -- the chain ends
+            // with the continuous inputs)
             const ldsd *lr = Lp + jc * nup;
-            for (int jj = 0; jj < nur; jj += 4) {
+            const int nsub = (t < 64 && ((S.fullfix >> t) & 1ull)) ? (nuc + 3) / 4 * 4 : nur;
+            for (int jj = 0; jj < nsub; jj += 4) {
                 const double c0 = lr[jj], c1 = lr[jj + 1], c2 = lr[jj + 2], c3 = lr[jj + 3];
                 const int s0 = nx + jj;
                 v -= c0 * bcast(v, s0 < WAVE ? s0 : WAVE - 1);
