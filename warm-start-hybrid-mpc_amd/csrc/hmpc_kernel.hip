@@ -17,8 +17,10 @@
 //     solves) stay in global memory (read-only, L2 resident) and are touched only when active;
 //   * reductions (complementarity, residual norms, step length) are wave shuffles plus one LDS
 //     exchange between waves -- no atomics, so a node's result does not depend on the batch it is in;
-//   * problems too large for LDS take the generic kernel's streaming form (lists and factor in global
-//     memory, Dims::kBig).
+//   * problems too large for LDS take the generic kernel's streaming form (Dims::kBig: lists and factor in a global
+//     slab, one node per CU with four waves): wave 0 runs the recursions -- the panel of the elimination, the sweeps
+//     of a solve on padded stage blocks staged by the other waves --, waves 1 .. 3 hold the tiles of the stage matrix
+//     on the matrix cores and prepare the next stage's while wave 0 eliminates (factor_tiles, kkt_sweeps_wave).
 //
 // Algorithm (same as the CPU oracle, oracle/hsde_qp.c): Mehrotra predictor-corrector on the
 // homogeneous embedding of the QP; each KKT solve is a Riccati sweep over the horizon with fixed
