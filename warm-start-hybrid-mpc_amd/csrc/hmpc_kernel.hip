@@ -1972,6 +1972,55 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
     FSTAMP_DECL;
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p);
     const int nxs = nx * (nx + 1) / 2, lms = LM_STAGE(nx, nu);
+    bool gdone = false;
+    if constexpr (D::kBig && D::kNT == 4 * WAVE) {
+        if (S.Cdn && p.ndp <= 32) {
+            // C' e of all stages at once on the matrix cores: (nz x dense rows) (dense rows x T), 16 x 16 tiles over the four
+            // waves, the rows of e gathered through the dense rows' index; the singleton rows (one term each) and the
+            // terminal-set rows are added by the lane that receives the entry.  (As a sum per entry -- 32 gathered terms,
+            // four entries per thread -- this was 21 k cycles of every solve.)
+            const int wl = lane & 63, wave = __builtin_amdgcn_readfirstlane(lane >> 6), r0 = wl >> 4, c0 = wl & 15;
+            const int tn = (nz + 15) >> 4, tt = (T + 15) >> 4;
+            for (int q = wave; q < tn * tt; q += D::kNW) {
+                const int ti = q / tt, tj = q - ti * tt;
+                const int i = ti * 16 + c0, ic = i < nz ? i : nz - 1; // first operand: column i of the dense rows
+                const int tcol = tj * 16 + c0, tc = tcol < T ? tcol : T - 1;
+                const ldsd *eb = S.e + tc * p.mreg;
+                double av[8], bv[8];
+#pragma unroll
+                for (int s2 = 0; s2 < 8; s2++) {
+                    const int k = 4 * s2 + r0, kc = k < p.ndp ? k : p.ndp - 1;
+                    const double x = S.Cdn[kc * nz + ic], y = eb[S.drow[kc]];
+                    av[s2] = k < p.ndp ? x : 0.0;
+                    bv[s2] = y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s2 = 0; s2 < 8; s2++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int j = ti * 16 + r0 + 4 * r;
+                    if (j < nz && tcol < T) {
+                        const int o = tcol * nz + j;
+                        const ldsd *er = S.e + tcol * p.mreg;
+                        double a = (gsrc ? gs * gsrc[o] : 0.0) + acc[r];
+                        for (int k = S.sptr[j]; k < S.sptr[j + 1]; k++) { // singleton rows of this column
+                            const int sr = S.srow[k];
+                            a += S.sval[sr] * er[sr];
+                        }
+                        if (S.term_on && tcol == T - 1) {
+                            const ldsd *vt = S.e + p.Toff;
+                            for (int k = 0; k < p.nT; k++) a += p.Ct[(size_t)k * nz + j] * vt[k];
+                        }
+                        S.g[o] = (useb ? S.g[o] : 0.0) - a;
+                    }
+                }
+            }
+            gdone = true;
+        }
+    }
+    if (!gdone)
     for (int o = lane; o < T * nz; o += D::kNT) {
         const int t = o / nz, j = o - t * nz;
         const double a = (gsrc ? gs * gsrc[o] : 0.0) + ccol_dot<D>(p, S, t, j, S.e);
