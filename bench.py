@@ -247,6 +247,19 @@ def other_configs(dev):
     r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: factor in a global slab; panel elimination on wave 0, tiles on the matrix cores)'
     r['frontier'] = '4096 distinct nodes: prefixes of a dive to a feasible leaf, every other one with one binary flipped (random prefixes of this generator are all infeasible)'
     out['random_mld_nx20_nu14_N30_dive_frontier_4096'] = r
+    # the same problem with the parent -> child hand-down (hmpc_warm): the tree a dive leaves behind (prefix chain of the
+    # leaf + one-flip siblings, 481 nodes, every node but the root with its parent in the frontier), tiled to 4096; the
+    # parents' records come from one untimed cold pass (as replay_frontier_4096_handdown on the headline system)
+    ft, pt = dive_tree(leaf[0])
+    m = len(ft)
+    reps_t = -(-4096 // m)
+    ftile = np.tile(ft, (reps_t, 1))[:4096]
+    ptile = np.concatenate([np.where(pt >= 0, pt + c * m, -1) for c in range(reps_t)])[:4096].astype(np.int32)
+    for key, par in (('random_mld_nx20_nu14_N30_dive_tree_4096', None), ('random_mld_nx20_nu14_N30_dive_tree_4096_handdown', ptile)):
+        r, _ = _device_rate(c4.qp, x0, ftile, dev, reps=3, warm=1, parent=par)
+        r['algorithmic_bytes_per_qp'] = c4.layout.bytes_per_qp()
+        r['frontier'] = 'dive tree: the %d nodes a depth-first dive has solved at its first leaf (prefix chain + siblings), tiled to 4096' % m
+        out[key] = r
     return out
 
 
@@ -407,6 +420,24 @@ def dive_frontier(leaf, count, seed):
             seen.add(row.tobytes())
             rows.append(row)
     return np.array(rows)
+
+
+def dive_tree(leaf):
+    """The tree a dive leaves behind: the chain of prefixes of the leaf (the root first) and, beside every prefix but the
+    root, its sibling -- the same prefix with its last binary flipped.  Returns (nodes [2 n + 1, n], parent index of each,
+    -1 for the root): what a depth-first search has solved when it reaches its first leaf, and the parents whose
+    records the hand-down gives to the children."""
+    n = leaf.size
+    rows, parent = [np.full(n, -1, np.int8)], [-1]
+    for d in range(1, n + 1):
+        p = np.full(n, -1, np.int8)
+        p[:d] = leaf[:d]
+        q = p.copy()
+        q[d - 1] = 1 - q[d - 1]
+        up = 2 * (d - 1) - 1 if d > 1 else 0          # the prefix one shorter (rows: root, then (prefix, sibling) pairs)
+        rows += [p, q]
+        parent += [up, up]
+    return np.array(rows), np.array(parent, dtype=np.int32)
 
 
 def shard(total, world, rank):
