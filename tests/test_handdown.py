@@ -111,3 +111,47 @@ def test_hand_down_in_the_device_pointer_form_and_in_the_tree_search():
     b = hip.feedforward(X0, printing_period=None, handdown=True)
     assert abs(a[2] - b[2]) <= 3 and abs(a[0].objective - b[0].objective) <= 1e-10
     assert np.array_equal(np.concatenate(a[0].variables['ub']), np.concatenate(b[0].variables['ub']))
+
+
+@pytest.mark.gpu
+def test_hand_down_on_the_streaming_kernel():
+    # BASELINE configs[4] (random MLD nx=20, nu=6+8, N=30; the streaming form of the generic kernel, its instantiation with
+    # the hand-down): the tree a dive leaves behind -- prefix chain of the first 64 binaries + one-flip siblings --, every node
+    # handed its parent's record; kernel and oracle verify the same handed-down sets and return the same records
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from bench import dive_tree
+    from helpers import random_mld, _NoBackend
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    mld, objective, x0 = random_mld()
+    T, nub, nx = 30, 8, 20
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    hip, orc = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=8)
+    Cj = np.array([mld.F[52 + 4 * j] for j in range(nub)])
+    leaf = np.full((1, T * nub), -1, np.int8)
+    for t in range(8):
+        r = orc.solve_batch(x0, leaf)
+        assert r['status'][0] == 0
+        leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+    short, parent = dive_tree(leaf[0, :64])
+    f = np.full((len(short), T * nub), -1, np.int8)
+    f[:, :64] = short
+    cold_k, cold_o = hip.solve_batch(x0, f), orc.solve_batch(x0, f)
+    assert np.array_equal(cold_k['status'], cold_o['status'])
+    good = (parent >= 0) & (cold_o['status'][np.maximum(parent, 0)] == 0) & (cold_o['polished'][np.maximum(parent, 0)] > 0) \
+        & (cold_k['polished'][np.maximum(parent, 0)] > 0)
+    idx = np.where(good, parent, -1).astype(np.int32)
+    a = hip.solve_batch(x0, f, warm=(cold_k['primal'], cold_k['dual'], idx))
+    b = orc.solve_batch(x0, f, warm=(cold_o['primal'], cold_o['dual'], idx))
+    assert np.array_equal(a['status'], b['status']) and np.array_equal(a['status'], cold_k['status'])
+    assert a['handed'].sum() >= 10
+    assert np.array_equal(a['handed'] > 0, b['polished'] > 4)          # (the oracle flags a verified hand-down as attempt 5)
+    opt = a['status'] == 0
+    np.testing.assert_allclose(a['obj'][opt], b['obj'][opt], rtol=2e-6, atol=1e-9)
+    both = opt & (a['polished'] > 0) & (b['polished'] > 0)
+    xs = (T + 1) * nx
+    assert np.abs(a['primal'][both][:, :xs] - b['primal'][both][:, :xs]).max() < 1e-7
+    assert a['iters'].mean() < cold_k['iters'].mean()
