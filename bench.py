@@ -471,6 +471,21 @@ def main():
                          '(the number it prints is not a scaling measurement)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # Called the way the one-GPU run is called (`python bench.py --gpus N ...`): start the N ranks as a CHILD process --
+        # one per GPU under torch.distributed.run, rendezvous on 127.0.0.1 -- before anything here touches the GPU (a
+        # process that has initialised the GPU must never be replaced by another), relay rank 0's JSON line (the ranks
+        # inherit stdout) and leave with the child's exit code.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        progress('spawning %d ranks: %s' % (args.gpus, ' '.join(cmd)))
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))))
+
     import torch
     import torch.distributed as dist
     from helpers import make_controller, random_prefix_frontier, load_fixture
@@ -479,8 +494,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (or call bench.py --gpus N without a launcher: it starts the ranks itself)' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     if args.rehearse_on_one_gpu:
@@ -585,6 +599,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # BASELINE configs[2] as written (ONE frontier of 1024 nodes over the ranks, node k to rank k mod N; strong scaling)
+    # beside the weak default, in the same multi-GPU run: same step (solve the shard, all-reduce the incumbent), same
+    # bracketing, max over the ranks
+    strong = None
+    if world > 1 and args.frontier_total == 0 and args.workload == 'cart_pole_n20' and args.frontier_kind == 'real_tree' and 1024 % world == 0:
+        xs_all, fs_all, _ = real_tree_frontier(ctrl, 1024, 0, load_fixture('cart_pole_with_walls')['x_max'], spread=spread)
+        mine = shard(1024, world, rank)
+        xs, fs = torch.from_numpy(np.ascontiguousarray(xs_all[mine])).to(dev), torch.from_numpy(np.ascontiguousarray(fs_all[mine])).to(dev)
+        Bs = len(mine)
+        outs = {k: v[:Bs] for k, v in out.items()}
+        ffs = torch.from_numpy((fs_all[mine] >= 0).all(axis=1)).to(dev)
+        ubs = torch.full((1,), float('inf'), dtype=torch.float64, device=dev)
+
+        def strong_step():
+            ctrl.qp.solve_batch_device(xs, fs, outs)
+            cand = torch.where(ffs, outs['obj'], torch.full_like(outs['obj'], float('inf')))
+            torch.minimum(ubs, cand.min().reshape(1), out=ubs)
+            dist.all_reduce(ubs, op=dist.ReduceOp.MIN)
+        for _ in range(args.warmup):
+            strong_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            strong_step()
+        barrier()
+        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        strong = {'frontier_total': 1024, 'nodes_per_gpu': Bs, 'ms_per_step': 1e3 * float(ts.item()) / args.steps,
+                  'qp_per_s': 1024 * args.steps / float(ts.item()), 'scaling': 'strong',
+                  'incumbent': float(ubs.item()), 'note': 'BASELINE configs[2]: 1024-node replay frontier sharded over the ranks, incumbent all-reduce every step'}
+
     status = out['status'].cpu().numpy()
     raw_iters = out['iters'].cpu().numpy()
     iters = raw_iters & 0xFFFF                           # bits 16..18 flag polished / weak / handed-down records
@@ -616,6 +661,7 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': ('strong' if args.frontier_total > 0 else 'weak') if not args.rehearse_on_one_gpu else 'rehearsal: all ranks on one GPU, not a measurement',
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'rccl_ranks': (dist.get_world_size() if world > 1 and dist.get_backend() == 'nccl' else (0 if world > 1 else 1)),
             'config': {'workload': ('cart_pole_with_walls N=%d, 4 binaries/step, %s' % (T, kind))
                        if args.workload != 'random_mld' else 'random MLD nx=20 nu=6+8 N=30 (SURVEY 8d C4), dive frontier',
                        'frontier_nodes_per_gpu': B, 'x0': x0_h.tolist() if x0_h.ndim == 1 else ([0., 0., 1., 0.] if args.states == 'nominal' and args.frontier_kind == 'real_tree'
@@ -639,6 +685,8 @@ def main():
                       'ipm_iters_mean_optimal': float(iters[status == 0].mean()) if (status == 0).any() else None,
                       'handed_down_verified': int(((raw_iters >> 18) & 1).sum())},
         }
+        if strong is not None:
+            line['configs2_strong_scaling_1024'] = strong
         if world == 1 and args.workload == 'cart_pole_n20':
             try:  # second kernel of the path (HBM bound), a few milliseconds
                 line['warm_start_shift'] = shift_bandwidth(ctrl, dev)

@@ -221,6 +221,11 @@ typedef struct hmpc_fleet hmpc_fleet;
 int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out);
 int hmpc_fleet_destroy(hmpc_fleet *f);
 int hmpc_fleet_reset(hmpc_fleet *f, int32_t k);
+/* Loop k has ended: its tree is dropped, it takes no part in further steps (no launches, no pool rows) until it is reset. */
+int hmpc_fleet_stop(hmpc_fleet *f, int32_t k);
+/* Rows of the multiplier pools in use / allocated.  Rows nobody references are reclaimed: hmpc_fleet_shift compacts, and
+ * hmpc_fleet_solve starts the pools from zero when every tree is cold. */
+int hmpc_fleet_rows(const hmpc_fleet *f, int64_t *used, int64_t *capacity);
 int hmpc_fleet_solve(hmpc_fleet *f, const double *x0 /* K x nx */, int32_t width, int32_t speculation, double tol, double *cost,
                      double *u0, double *x1, int32_t *solves, int32_t *leaves);
 int hmpc_fleet_shift(hmpc_fleet *f, const double *e0 /* K x nx */, int32_t *cover, int32_t *reopened);
@@ -249,11 +254,18 @@ typedef struct hmpc_comm hmpc_comm;
 int hmpc_comm_unique_id(void *id128 /* 128 bytes out */);
 int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, const void *id128, hmpc_comm **out);
 int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub /* in/out */, int32_t *open /* in/out */);
+/* The same exchange on device memory and on the caller's stream: pair_device[0] = upper bound, pair_device[1] =
+ * -(open candidates), reduced in place (MIN); enqueued, not waited for -- work launched on `stream` afterwards sees the
+ * global pair.  `stream` is a hipStream_t (NULL: the default stream). */
+int hmpc_allreduce_incumbent_device(hmpc_comm *c, double *pair_device /* 2 doubles, in/out */, void *stream);
 /* After the last round (once per search; every rank calls it): which rank owns the global incumbent, and its binary
  * assignment on every rank.  In: *ub this rank's best upper bound (+INFINITY: none), assignment its incumbent's nbytes
  * bytes (T*nub binaries for this solver; ignored on ranks that do not own the winner).  Out: *ub the global best, *owner
  * the lowest rank that holds it (-1: no rank has an incumbent, the MIQP is infeasible; assignment untouched), assignment
- * the owner's bytes on every rank (one ncclBroadcast).  SURVEY.md 8(b)/(e). */
+ * the owner's bytes on every rank (one ncclBroadcast).  SURVEY.md 8(b)/(e).
+ * nbytes <= T*nub of the handle the communicator was created on.  A bound of -INFINITY or NaN on any rank (the abort
+ * convention above) makes EVERY rank return HMPC_EINVAL after the first reduction; any other failure between the
+ * collectives aborts the communicator (the peers are already waiting in the next one). */
 int hmpc_publish_incumbent(hmpc_comm *c, double *ub /* in/out */, int8_t *assignment /* in/out */, int32_t nbytes, int32_t *owner);
 int hmpc_comm_destroy(hmpc_comm *c);
 

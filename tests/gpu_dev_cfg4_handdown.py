@@ -32,7 +32,7 @@ b = orc.solve_batch(x0, f, warm=(cold_o['primal'], cold_o['dual'], idx))
 opt = b['status'] == 0
 print('%d nodes, %d handed a parent; status equal %s (vs cold %s); optimal %d; handed-down verified kernel %d oracle %d; iterations kernel %.2f (cold %.2f)'
       % (len(f), int(good.sum()), np.array_equal(a['status'], b['status']), np.array_equal(a['status'], cold_k['status']), int(opt.sum()),
-         int(a['handed'].sum()), int((b['polished'] > 4).sum()) if 'polished' in b else -1, a['iters'].mean(), cold_k['iters'].mean()))
+         int(a['handed'].sum()), int((b['polished'] == 64).sum()) if 'polished' in b else -1, a['iters'].mean(), cold_k['iters'].mean()))
 both = opt & (a['polished'] > 0) & (b['polished'] > 0)
 xs = (T + 1) * nx
 print('objective %.1e, x of vertex records %.1e (%d), vs the cold records %.1e'

@@ -7,7 +7,9 @@ Rank 0 creates the communicator id (hmpc_comm_unique_id) and writes its 128 byte
 every rank then creates its handle on device RANK and the communicator (hmpc_comm_create) and goes through
   1. hmpc_allreduce_incumbent   MIN semantics of (upper bound, open candidates)
   2. the abort convention       one rank contributes -inf, every rank reads -inf
-  3. hmpc_publish_incumbent     owner = lowest rank that holds the best bound, its assignment on every rank; a tie; no incumbent
+  3. hmpc_publish_incumbent     owner = lowest rank that holds the best bound, its assignment on every rank; a tie; no incumbent;
+                                a bound of -inf on one rank: HMPC_EINVAL on every rank
+  4. hmpc_allreduce_incumbent_device   the exchange of 1. on device memory, enqueued on the caller's stream
 and prints one JSON line with what it saw."""
 import ctypes
 import json
@@ -56,11 +58,30 @@ def main():
         qp._check(lib.hmpc_publish_incumbent(comm, ctypes.byref(a), bits.ctypes.data, bits.size, ctypes.byref(owner)))
         return a.value, owner.value, bits.tolist()
 
+    def allreduce_device(ub, n_open):
+        # the same exchange on device memory and on the caller's stream (hmpc_allreduce_incumbent_device): nothing copied,
+        # nobody waits until this test reads the pair back
+        import torch
+        dev = torch.device('cuda', rank)
+        pair = torch.tensor([ub, -float(n_open)], dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        qp._check(lib.hmpc_allreduce_incumbent_device(comm, ctypes.c_void_p(pair.data_ptr()), ctypes.c_void_p(stream.cuda_stream)))
+        after = pair * 1.0                                               # (work enqueued on the same stream sees the global pair)
+        stream.synchronize()
+        return float(after[0].item()), int(round(-float(after[1].item())))
+
+    def publish_error(ub):
+        a, owner = ctypes.c_double(ub), ctypes.c_int32(-7)
+        bits = np.zeros(40, dtype=np.int8)
+        return int(lib.hmpc_publish_incumbent(comm, ctypes.byref(a), bits.ctypes.data, bits.size, ctypes.byref(owner)))
+
     seen['min'] = allreduce(3.0 - rank, 5 if rank == 0 else 0)             # ranks hold 3, 2, ...: the last rank wins
+    seen['min_device'] = allreduce_device(3.0 - rank, 5 if rank == 0 else 0)
     seen['abort'] = allreduce(float('-inf') if rank == nranks - 1 else 1.0, 1)
     seen['publish'] = publish(2.5 - 0.5 * rank, rank)                      # the last rank owns the incumbent
     seen['tie'] = publish(1.0, 10 + rank)                                  # equal bounds: the lowest rank
     seen['none'] = publish(float('inf'), 20 + rank)                        # no incumbent anywhere
+    seen['poisoned'] = publish_error(float('-inf') if rank == nranks - 1 else 1.0)   # every rank gets the error, none blocks
     # the solver still works beside the communicator
     r = qp.solve_batch(np.array([0., 0., .5, 0.]), np.full((1, 40), -1, dtype=np.int8))
     seen['root_status'] = int(r['status'][0])

@@ -54,8 +54,11 @@ def test_speculative_expansion_in_the_fleet_changes_launches_not_results():
     plain = a.closed_loop(X0, 8, errors, frontier_width=1)
     spec = b.closed_loop(X0, 8, errors, frontier_width=1, speculation=4, cold_speculation=4)
     np.testing.assert_allclose(spec['costs'], plain['costs'], rtol=1e-9, atol=1e-12)
-    assert np.array_equal(spec['len_ws'], plain['len_ws']) and np.array_equal(spec['reopened'], plain['reopened'])
-    assert np.max(np.abs(spec['nodes_ws'] - plain['nodes_ws'])) <= 4           # (kernel variant differs with the batch size)
+    # (kernel variant differs with the batch size -- 1 / 2 / 4 waves per node --, and which infeasibility proofs survive a
+    # shift depends on the ray: a leaf whose shifted dual objective lies at the margin is reopened by one variant and not
+    # by the other; every reopened leaf is one more solve of the next step)
+    assert np.array_equal(spec['len_ws'], plain['len_ws']) and np.max(np.abs(spec['reopened'] - plain['reopened'])) <= 2
+    assert np.max(np.abs(spec['nodes_ws'] - plain['nodes_ws'])) <= 4
     assert b.stats()['rounds'] < a.stats()['rounds'] / 2 and b.stats()['launched'] > a.stats()['launched']
     # dive prediction (speculation < 0): the rest of a dive, predicted from the parent's rounded relaxed binaries, and the
     # sibling of every step ride along -- linear in the depth; the cold start takes a handful of launches
@@ -132,6 +135,7 @@ def test_incumbent_exchange_over_rccl_between_two_gpus(tmp_path):
     seen = [json.loads(o.strip().splitlines()[-1]) for o, _ in outs]
     for s in seen:
         assert s['min'] == [2.0, 5]                                     # smallest bound, largest number of open candidates
+        assert s['min_device'] == [2.0, 5] and s['poisoned'] == -1      # (HMPC_EINVAL on EVERY rank)
         assert s['abort'][0] == '-Infinity' or s['abort'][0] == float('-inf')
         assert s['publish'][0] == 2.0 and s['publish'][1] == 1 and s['publish'][2] == [1] * 40
         assert s['tie'][0] == 1.0 and s['tie'][1] == 0 and s['tie'][2] == [10] * 40
@@ -151,5 +155,6 @@ def test_incumbent_publication_over_rccl_with_one_rank(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     s = json.loads(r.stdout.strip().splitlines()[-1])
     assert s['min'] == [3.0, 5] and s['abort'][0] == float('-inf')
+    assert s['min_device'] == [3.0, 5] and s['poisoned'] == -1
     assert s['publish'][:2] == [2.5, 0] and s['publish'][2] == [0] * 40
     assert s['tie'][:2] == [1.0, 0] and s['none'][1] == -1 and s['root_status'] == 0

@@ -24,23 +24,18 @@ RTOL = 1e-5   # north_star: continuous trajectories within 1e-5 relative -- ONE 
 
 
 ETOL, EFLOOR = 1e-5, 1e-6   # element-wise: every component within 1e-5 of its own size (components below 1e-6: of 1e-6)
-# Records WITHOUT the polished flag (HMPC_ITERS_POLISHED clear: the active-set polish did not verify, the record is the
-# interior-point iterate that met the stopping test -- a documented, distinct outcome, include/hmpc.h) are only
-# reproducible to the accuracy of such an iterate.  With the barrier parameter at its floor (mu < 1e-11, exit
-# "exhausted") the objective is within ~1e-6 relative of the optimum; for a cost of curvature 2 (Q = I, R = [I 0]: the
-# random MLD) two such points may lie 2 sqrt(eps) ~ 4e-3 apart, and two runs of the SAME algorithm whose sums are
-# associated differently (kernel and oracle, or two versions of the kernel) do end 1e-5 .. 6.5e-4 apart -- measured on
-# the dive frontier of BASELINE configs[4], the one configuration where a quarter of the optimal nodes end that way
-# (1.4e-4 there, 6.5e-4 on the other random shapes below; round 2's kernel: 3.1e-5 on 96 nodes, its 48-node test passed
-# at 1e-5 by the luck of the sample).  Such records are
-# held to: the same status, objectives within 2e-6, a KKT certificate of their own at 5e-6 (kkt_checks.check_solution:
-# feasible, dual feasible, duality gap -- no reference involved), and trajectories within 1e-3 norm-wise of the
-# oracle's.  Every polished record -- all optimal nodes of the cart-pole systems -- is held to RTOL element-wise.
-ITERATE_RTOL = 1e-3
+# Records WITHOUT the polished flag (HMPC_ITERS_POLISHED clear: the active-set polish did not verify, the record is an
+# interior-point iterate -- a documented, distinct outcome, include/hmpc.h) are held to the SAME tolerance since round 4.
+# Until round 3 such a record was the iterate at gap 1e-8 .. 1e-6 (2 - 7 % of the optimal nodes of BASELINE configs[4]),
+# reproducible to ~sqrt(gap) = 1e-4 only, and this file carried an ITERATE_RTOL = 1e-3 for them.  Now a solve whose last
+# polish attempt fails tightens its stopping tolerance (1e-10, then 1e-12) and tries again from the tighter iterate
+# (tolerance escalation, hmpc_kernel.hip ipm_solve / oracle/hsde_qp.c solve_one): every optimal node of the configs[4]
+# frontiers polishes, and the rare record that still does not is an iterate at gap 1e-12 -- compared norm-wise at RTOL
+# (element-wise comparison is for vertex records: a component of 1e-6 in an iterate is not accurate to 1e-11).
 WORST = {'norm': 0.0, 'element': 0.0, 'dense': 0.0, 'iterate': 0.0}   # largest deviations seen in this session (printed at the end)
 
 
-def _rel(a, b, elementwise=True):
+def _rel(a, b, elementwise=True, efloor=None):
     """Largest deviation of a from b per row, relative to the row's largest entry of b (floor 1e-2) -- and, beside
     that norm-wise measure, the element-wise one: every component relative to its OWN size (floor EFLOOR), so that a
     small component (a pole angle of 1e-3 next to a velocity of 1) is held to the same relative accuracy."""
@@ -52,7 +47,7 @@ def _rel(a, b, elementwise=True):
         WORST['iterate'] = max(WORST['iterate'], norm.max())   # (records without the polished flag)
         return norm
     WORST['norm'] = max(WORST['norm'], norm.max())
-    elem = np.max(np.abs(a - b) / np.maximum(np.abs(b), EFLOOR), axis=1)
+    elem = np.max(np.abs(a - b) / np.maximum(np.abs(b), EFLOOR if efloor is None else efloor), axis=1)
     WORST['element'] = max(WORST['element'], elem.max())
     return np.maximum(norm, elem * (RTOL / ETOL))
 
@@ -95,7 +90,7 @@ def _dense_check(ctrl, T, x0, fix, rec, sample=64, seed=0):
     return opt.size
 
 
-def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True, RTOL=RTOL):
+def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True, efloor=None):
     """States, the inputs the cost is strictly convex in (unique at every node), and -- where every binary is
     fixed, the nodes an incumbent comes from -- ALL inputs, at RTOL.  Inputs no cost term sees are not unique in
     a relaxation: a vertex solution and Gurobi's would differ there as well."""
@@ -104,16 +99,16 @@ def _trajectories_close(ctrl, T, fix, pa, pb, what='', elementwise=True, RTOL=RT
     ua, ub = pa[:, (T + 1) * nx:].reshape(-1, T, nu), pb[:, (T + 1) * nx:].reshape(-1, T, nu)
     # (element-wise -- every component to 1e-5 of its own size -- where both sides return the vertex of an active set;
     # an interior-point iterate that meets the stopping test is compared norm-wise only)
-    assert _rel(xa, xb, elementwise).max(initial=0) < RTOL, (what, 'x', _rel(xa, xb, elementwise).max())
+    assert _rel(xa, xb, elementwise, efloor).max(initial=0) < RTOL, (what, 'x', _rel(xa, xb, elementwise, efloor).max())
     for j in determined_inputs(ctrl):
-        assert _rel(ua[:, :, j], ub[:, :, j], elementwise).max(initial=0) < RTOL, (what, 'u', j, _rel(ua[:, :, j], ub[:, :, j], elementwise).max())
+        assert _rel(ua[:, :, j], ub[:, :, j], elementwise, efloor).max(initial=0) < RTOL, (what, 'u', j, _rel(ua[:, :, j], ub[:, :, j], elementwise, efloor).max())
     if fix is not None:
         full = (np.asarray(fix) >= 0).all(axis=1)
         if full.any():
-            assert _rel(ua[full].reshape(full.sum(), -1), ub[full].reshape(full.sum(), -1), elementwise).max() < RTOL, (what, 'u of fully fixed nodes')
+            assert _rel(ua[full].reshape(full.sum(), -1), ub[full].reshape(full.sum(), -1), elementwise, efloor).max() < RTOL, (what, 'u of fully fixed nodes')
 
 
-def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
+def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None, efloor=None):
     """a: records of the HIP path, b: of the oracle.  With x0 (and fix) the polished records of the HIP path are also
     checked against the dense active-set solve, which shares no code with either."""
     assert np.array_equal(a['status'], b['status']), np.flatnonzero(a['status'] != b['status'])
@@ -128,13 +123,12 @@ def _compare(ctrl, a, b, T, fix=None, min_polished=1.0, x0=None):
     raw = fin & ~pol
     np.testing.assert_allclose(a['obj'][pol], b['obj'][pol], rtol=1e-8, atol=1e-11)
     np.testing.assert_allclose(a['dual_obj'][pol], b['dual_obj'][pol], rtol=1e-6, atol=1e-9)   # (evaluated from multipliers of order 1e2)
-    np.testing.assert_allclose(a['obj'][raw], b['obj'][raw], rtol=2e-6, atol=1e-9)
-    np.testing.assert_allclose(a['dual_obj'][raw], b['dual_obj'][raw], rtol=2e-6, atol=1e-9)
-    if min_polished is not None:
-        assert pol.sum() >= min_polished * fin.sum(), (pol.sum(), fin.sum())
-    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[pol], a['primal'][pol], b['primal'][pol], 'polished')
-    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[raw], a['primal'][raw], b['primal'][raw], 'iterate', elementwise=False,
-                        RTOL=ITERATE_RTOL)
+    np.testing.assert_allclose(a['obj'][raw], b['obj'][raw], rtol=1e-8, atol=1e-11)      # (iterates at gap <= 1e-10 since round 4)
+    np.testing.assert_allclose(a['dual_obj'][raw], b['dual_obj'][raw], rtol=1e-6, atol=1e-9)
+    if min_polished is not None:   # (one record is always allowed for: 48-node frontiers have ~40 optimal nodes)
+        assert pol.sum() >= min(min_polished * fin.sum(), fin.sum() - 1), (pol.sum(), fin.sum())
+    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[pol], a['primal'][pol], b['primal'][pol], 'polished', efloor=efloor)
+    _trajectories_close(ctrl, T, None if fix is None else np.asarray(fix)[raw], a['primal'][raw], b['primal'][raw], 'iterate', elementwise=False)
     inf = a['status'] == 1
     assert np.all(np.isinf(a['obj'][inf])) and np.all(np.isnan(a['primal'][inf]))
     # Farkas rays are normalised to a unit largest multiplier on both sides
@@ -363,7 +357,7 @@ def test_other_problem_shapes_and_size_limit():
     hip, orc = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=8)
     fix = random_prefix_frontier(8, 3, 128, p_one=0.3)
     fix[0, :] = -1
-    _compare(ctrl, hip.solve_batch(x0, fix), orc.solve_batch(x0, fix), 8, fix, min_polished=0.8)
+    _compare(ctrl, hip.solve_batch(x0, fix), orc.solve_batch(x0, fix), 8, fix, min_polished=0.99, x0=x0)
 
 
 def test_streaming_kernel_baseline_config4():
@@ -385,26 +379,28 @@ def test_streaming_kernel_baseline_config4():
         r = orc.solve_batch(x0, leaf)
         assert r['status'][0] == 0
         leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
-    rng = np.random.default_rng(0)
-    fix = np.full((256, T * nub), -1, np.int8)
-    for k in range(1, 256):
-        d = int(rng.integers(1, T * nub + 1))
-        fix[k, :d] = leaf[0, :d]
-        if k % 2 == 0:
-            j = int(rng.integers(0, d))
-            fix[k, j] = 1 - fix[k, j]
+    # BASELINE's size: the 4096 DISTINCT nodes of the bench's dive frontier (bench.dive_frontier; until round 3: 256 nodes)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import dive_frontier
+    fix = dive_frontier(leaf[0], 4096, 0)
+    orc.threads = os.cpu_count() or 8
     a, b = hip.solve_batch(x0, fix), orc.solve_batch(x0, fix)
     assert hip.launch_info()[1] > 100 * 1024          # the streaming carve: vectors only, still most of a CU
     # this generator leaves the binaries out of the cost (R = [I 0], as the reference does): states and continuous
-    # inputs are unique and compared at RTOL like everywhere else, the relaxed binaries are not
-    _compare(ctrl, a, b, T, fix, min_polished=0.6)   # (the active sets of this generator's relaxations are hard: 6 rounds x 3 attempts)
-    # the records that are NOT polished certify themselves (no reference involved): feasible, dual feasible, duality gap
-    raw = np.flatnonzero((a['status'] == 0) & (a['polished'] == 0))
-    assert raw.size > 0
-    for i in raw:
+    # inputs are unique and compared at RTOL like everywhere else, the relaxed binaries are not.  Every record at the one
+    # tolerance; >= 99 % of the optimal nodes polished (measured: all of them, on both sides -- the tolerance escalation
+    # of round 4; until then 2 % returned an iterate 1e-4 off); a seeded sample of the kernel's polished records against
+    # the dense active-set solve, which shares no code with kernel or oracle.
+    # (element-wise floor 1e-5 here: the states of this system decay to 1e-7 along the horizon, and a vertex computed by the
+    # method of multipliers at rho = 1e5 is good to ~1e-11 absolute -- measured worst 3.5e-11 on a component of 1e-7 among
+    # 3631 x 620 -- which is 1e-5 of a component of 1e-6; norm-wise the worst deviation is 3.7e-8)
+    _compare(ctrl, a, b, T, fix, min_polished=0.99, x0=x0, efloor=1e-5)
+    # a record that is NOT polished certifies itself (no reference involved): feasible, dual feasible, duality gap
+    for i in np.flatnonzero((a['status'] == 0) & (a['polished'] == 0)):
         sol = SubproblemSolution.from_rows(ctrl.layout, fix[i], a['obj'][i], a['dual_obj'][i], a['status'][i], a['primal'][i], a['dual'][i])
         ident = {(k // nub, k % nub): float(v) for k, v in enumerate(fix[i]) if v >= 0}
-        assert check_solution(ctrl, sol, ident, x0, tol=5e-6) == 'optimal'   # (exit at the barrier floor: residuals <= 1e-6 in the SCALED problem; measured 2.1e-6 unscaled)
+        assert check_solution(ctrl, sol, ident, x0, tol=5e-6) == 'optimal'
     assert (a['status'] == 0).sum() >= 1 and (a['status'] == 1).sum() >= 1
     # a problem whose vectors alone exceed a CU's LDS is still refused loudly
     huge = HybridModelPredictiveController(mld, 60, objective, None, backend=_NoBackend())
@@ -444,7 +440,7 @@ def test_streaming_kernel_other_shapes(monkeypatch, nx, nuc, nub, T, seed):
                 fix[k, j] = 1 - fix[k, j]
     a, b = hip.solve_batch(x0, fix), orc.solve_batch(x0, fix)
     assert hip.launch_info()[0] >= 1
-    _compare(ctrl, a, b, T, fix, min_polished=0.6)
+    _compare(ctrl, a, b, T, fix, min_polished=0.99, x0=x0, efloor=1e-5)
     assert (a['status'] == 0).sum() >= 1
 
 
@@ -517,6 +513,70 @@ def test_device_warm_start_shift_matches_host_forms():
     for w, c in zip(warm, cold):
         assert np.isclose(w['objective'], c['objective'], rtol=1e-5, atol=1e-8) or (np.isinf(w['objective']) and np.isinf(c['objective']))
         assert w['solves'] < c['solves']
+
+
+def test_warm_start_properties_on_gpu():
+    # The reference's warm-start properties (warm_start_hmpc/test/test_controller.py:122-163) on the HIP backend: leaves
+    # produced by the kernel, shifted (a) by the host form behind construct_warm_start and (b) by hmpc_shift_kernel;
+    # checked through the reference's checkers restated in kkt_checks.py, not through the oracle:
+    #   implied lower bounds <= the optimum of the node at the next state; shifted multipliers dual feasible
+    #   (stationarity 1e-5 relative, signs); dual objective of a shifted multiplier == node.lb (1e-6) for finite bounds,
+    #   > 0 for shifted infeasibility proofs; warm == cold cost.
+    from kkt_checks import dual_residuals, dual_objective
+    from warm_start_hmpc_amd.batched import BatchedMPC
+    from warm_start_hmpc_amd.subproblem_solution import DualSolution
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    sol, leaves, solves, _ = hip.feedforward(X0, printing_period=None)
+    np.random.seed(1)
+    uc0, ub0 = sol.variables['uc'][0], sol.variables['ub'][0]
+    e0 = np.random.randn(hip.mld.nx) * .001
+    x1 = hip.mld.A.dot(X0) + hip.mld.B.dot(np.concatenate((uc0, ub0))) + e0
+    ws = hip.construct_warm_start(leaves, X0, uc0, ub0, e0)[0]
+    assert len(ws) == 77 and is_disjoint_cover(hip, ws)         # published cover size (solve_log_sd_0.000.log:8)
+    # the nodes of the cover at the next state, one launch
+    fix = np.array([hip._fix_vector(n.identifier) for n in ws], dtype=np.int8)
+    at_x1 = hip.qp.solve_batch(x1, fix)
+    assert np.all(at_x1['status'] <= 1)
+
+    def properties(identifier, lb, variables, x):
+        zero, nonneg = dual_residuals(hip, variables)
+        assert np.max(np.abs(zero)) < 1e-5 * (1 + np.max(np.abs(np.concatenate(variables['mu']))))
+        assert np.min(nonneg) >= -1e-9
+        obj = max(0., dual_objective(hip, variables, identifier, x))
+        if np.isinf(lb):
+            assert obj > 0.
+            return 1
+        assert abs(obj - lb) < 1e-6
+        return 0
+    kept = 0
+    for k, node in enumerate(ws):
+        assert at_x1['obj'][k] >= node.lb - 1e-7                # implied bounds are valid (inf: the node IS infeasible)
+        if node.extra.dual is not None:
+            kept += properties(node.identifier, node.lb, node.extra.dual.variables, x1)
+    assert kept >= 70                                           # the Farkas proofs survive the shift (73-75 of 77)
+    # (b) the same leaves through the shift kernel
+    bm = BatchedMPC(hip)
+    assert bm.device_shift
+    res = bm.feedforward_many(X0[None], None, frontier_width=1)
+    r = res[0]
+    u0 = np.concatenate((r['uc'][0], r['ub'][0]))
+    assert np.array_equal(np.round(r['ub'][0]), np.round(ub0))
+    dev = bm.construct_warm_start_many([r['leaves']], X0[None], u0[None], e0[None])[0]
+    x1d = hip.mld.A.dot(X0) + hip.mld.B.dot(u0) + e0
+    assert len(dev) == 77
+    at_x1d = hip.qp.solve_batch(x1d, dev.fix)
+    kept = 0
+    for k in range(len(dev)):
+        assert at_x1d['obj'][k] >= dev.lb[k] - 1e-7
+        if dev.has_dual[k]:
+            d = DualSolution.from_row(hip.layout, dev.dobj[k], dev.dual[k])
+            ident = {(q // hip.mld.nub, q % hip.mld.nub): float(v) for q, v in enumerate(dev.fix[k]) if v >= 0}
+            kept += properties(ident, dev.lb[k], d.variables, x1d)
+    assert kept >= 70
+    cold = hip.feedforward(x1d, printing_period=None)
+    warm = hip.feedforward(x1d, printing_period=None, warm_start=ws)
+    assert warm[0].objective == cold[0].objective               # test_controller.py:165-170 (assertEqual)
+    assert warm[2] <= 25 and cold[2] >= 150                     # published: 10-17 warm, 158-161 cold
 
 
 def test_replayed_real_frontier():

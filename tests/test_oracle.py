@@ -225,6 +225,41 @@ def test_polish_settles_nearly_dependent_active_sets():
         assert np.max(np.abs(w[:n] - res['primal'][b][:n])) / max(1e-2, np.max(np.abs(w[:n]))) < 1e-7
 
 
+def test_degenerate_relaxations_polish_after_tolerance_escalation():
+    # BASELINE configs[4] (random MLD nx=20, nu=6+8, N=30): relaxations without strict complementarity -- ~100 rows whose
+    # slack AND multiplier vanish.  Read from an iterate of gap 1e-8 the active-set exchange of the polish cycles on 7 % of
+    # the nodes of a dive tree (round 3: they returned the interior-point iterate, 1e-4 off); with the tolerance escalation
+    # of round 4 (solve_one: a failed last attempt tightens the stopping tolerance and tries again) every one polishes, and
+    # the result is the solution of the dense active-set solve, which shares no code with the oracle.
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import dive_tree
+    from helpers import random_mld
+    from dense_qp import dense_qp, active_set_primal
+    mld, objective, x0 = random_mld()
+    T, nub, nx = 30, 8, 20
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    orc = OracleBatchedQP(ctrl.problem_data(), threads=8)
+    Cj = np.array([mld.F[52 + 4 * j] for j in range(nub)])
+    leaf = np.full((1, T * nub), -1, np.int8)
+    for t in range(T):
+        r = orc.solve_batch(x0, leaf)
+        leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+    fix = dive_tree(leaf[0])[0][:120]
+    res = orc.solve_batch(x0, fix)
+    opt = np.flatnonzero(res['status'] == 0)
+    assert opt.size > 100 and np.all(res['polished'][opt] > 0), (opt.size, int((res['polished'][opt] == 0).sum()))
+    escalated = opt[res['polished'][opt] > 4]               # (attempt numbers beyond the regular three + the last one)
+    assert escalated.size >= 10, escalated.size              # (round 3 left 32 of these 120 unpolished)
+    dq = dense_qp(ctrl)
+    n = (T + 1) * nx
+    for b in escalated[:6]:
+        w, resid = active_set_primal(ctrl, dq, x0, fix[b], res['dual'][b])
+        assert resid < 1e-10
+        assert np.max(np.abs(w[:n] - res['primal'][b][:n])) / max(1e-2, np.max(np.abs(w[:n]))) < 1e-7
+
+
 def test_product_configuration_against_the_tight_one():
     # The product polishes from an iterate that is only good to 1e-4; the result must still be THE vertex solution.
     # Random prefixes with one initial state per node; this set holds nodes on which a clipped multiplier of -5e-8

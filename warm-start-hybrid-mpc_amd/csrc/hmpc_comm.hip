@@ -72,7 +72,11 @@ extern "C" int hmpc_comm_create(hmpc_handle *h, int32_t nranks, int32_t rank, co
         delete c;
         return fail(HMPC_EDEVICE, msg);
     }
+    // (everything a later collective needs is allocated here: an allocation that fails between two collectives would
+    // leave the other ranks waiting in the next one)
+    c->cap_bytes = (size_t)std::max(1, h->dp.T * h->dp.nub);
     if (hipMalloc((void **)&c->d_pair, 2 * sizeof(double)) != hipSuccess || hipHostMalloc((void **)&c->h_pair, 2 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&c->d_bytes, c->cap_bytes) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         hmpc_comm_destroy(c);
         return fail(HMPC_EDEVICE, "comm: cannot allocate");
@@ -98,6 +102,21 @@ extern "C" int hmpc_allreduce_incumbent(hmpc_comm *c, double *ub, int32_t *open)
     return HMPC_OK;
 }
 
+// The same exchange without the host in it: pair[0] = upper bound, pair[1] = -(open candidates), two float64 in DEVICE
+// memory, reduced in place (MIN) by a collective enqueued on the caller's stream -- the stream the solves of the round were
+// launched on --; nothing is copied and nobody waits: the next launch on that stream sees the global bound.  (The
+// host-pointer form above costs a copy up, a copy down and a stream synchronisation per round: ~30 us of host time in
+// which the GPU idles; at 128 nodes per GPU -- BASELINE configs[2] on 8 GPUs -- a round is ~2 ms.)
+extern "C" int hmpc_allreduce_incumbent_device(hmpc_comm *c, double *pair_device, void *stream)
+{
+    g_err.clear();
+    if (!c || !pair_device) return fail(HMPC_EINVAL, "comm: null argument");
+    HIPCHK(hipSetDevice(c->h->device));
+    const int rc = c->AllReduce(pair_device, pair_device, 2, /* ncclFloat64 */ 8, /* ncclMin */ 3, c->comm, (hipStream_t)stream);
+    if (rc != 0) return fail(HMPC_EDEVICE, std::string("comm: ncclAllReduce failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?"));
+    return HMPC_OK;
+}
+
 // Who owns the global incumbent, and its binary assignment on every rank ("pack (ub, rank) ... or
 // follow with ncclBroadcast of the <= T nub byte winning identifier from the owner").  One all-reduce (MIN) of
 // (ub, rank if this rank's bound equals ... ) cannot be had in one step without knowing the minimum, so: MIN over the
@@ -118,23 +137,22 @@ extern "C" int hmpc_publish_incumbent(hmpc_comm *c, double *ub, int8_t *assignme
         out = c->h_pair[0];
         return HMPC_OK;
     };
-    const double mine = *ub;
+    // (a failure between two collectives aborts the communicator: the peers are already in the next one.  Nothing below
+    // can fail for a reason of this rank alone -- the staging buffer is allocated at creation --, and a bound that is no
+    // bound is seen by EVERY rank after the first reduction: all of them return the error together)
+    if ((size_t)nbytes > c->cap_bytes) return fail(HMPC_EINVAL, "comm: assignment longer than T * nub of the handle the communicator was created on");
+    const double mine = (*ub == *ub) ? *ub : -std::numeric_limits<double>::infinity(); // (NaN: no order under MIN)
     double best = 0, who = 0;
     int rc;
     if ((rc = reduce_min(mine, best))) return rc;
+    if (best == -std::numeric_limits<double>::infinity())
+        return fail(HMPC_EINVAL, "comm: a rank published -inf / NaN as its upper bound (the abort convention of hmpc_allreduce_incumbent): no incumbent is published");
     // the lowest rank among those that hold the best bound (ties between ranks are possible: equal optima)
     if ((rc = reduce_min((mine == best && std::isfinite(mine)) ? (double)c->rank : (double)c->nranks, who))) return rc;
     *ub = best;
     if (who >= (double)c->nranks) { *owner = -1; return HMPC_OK; } // no rank has an incumbent: the problem is infeasible
     *owner = (int32_t)who;
     if (nbytes == 0) return HMPC_OK;
-    if ((size_t)nbytes > c->cap_bytes) {
-        if (c->d_bytes) (void)hipFree(c->d_bytes);
-        c->d_bytes = nullptr;
-        c->cap_bytes = 0;
-        HIPCHK(hipMalloc((void **)&c->d_bytes, (size_t)nbytes));
-        c->cap_bytes = (size_t)nbytes;
-    }
     if (c->rank == *owner) HIPCHK(hipMemcpyAsync(c->d_bytes, assignment, (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     rc = c->Broadcast(c->d_bytes, c->d_bytes, (size_t)nbytes, /* ncclInt8 */ 0, *owner, c->comm, c->stream);
     if (rc != 0) return fail(HMPC_EDEVICE, std::string("comm: ncclBroadcast failed: ") + (c->GetErrorString ? c->GetErrorString(rc) : "?"));

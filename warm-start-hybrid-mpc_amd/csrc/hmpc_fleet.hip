@@ -249,6 +249,26 @@ extern "C" int hmpc_fleet_reset(hmpc_fleet *f, int32_t k)
     return HMPC_OK;
 }
 
+// Loop k has ended (its MIQP had no solution, or its caller has no further use for it): its tree is dropped and the loop
+// takes no part in further steps -- no launches, no rows held in the pools -- until hmpc_fleet_reset makes it cold again.
+extern "C" int hmpc_fleet_stop(hmpc_fleet *f, int32_t k)
+{
+    if (!f || k < 0 || k >= f->K) return fail(HMPC_EINVAL, "fleet: bad loop index");
+    tree_reset_cold(f->trees[k], f->h->dp.T * f->h->dp.nub);
+    f->trees[k].running = false;
+    return HMPC_OK;
+}
+
+// Rows of the pools in use.  (For tests and reports: a fleet that is reset and solved at every step -- the cold searches
+// of a closed-loop study -- must not grow with the number of steps.)
+extern "C" int hmpc_fleet_rows(const hmpc_fleet *f, int64_t *used, int64_t *capacity)
+{
+    if (!f) return fail(HMPC_EINVAL, "fleet: null argument");
+    if (used) *used = (int64_t)f->used;
+    if (capacity) *capacity = (int64_t)f->cap_rows;
+    return HMPC_OK;
+}
+
 // One MPC step of every running loop: branch and bound from the loop's current tree (the root for a cold loop).
 // speculation = k > 0: with every candidate that has to be solved, its descendants through the next k binaries (2 + 4 +
 // ... + 2^k nodes) ride in the same launch; their results wait in a per-tree cache and are consumed -- unchanged -- if and
@@ -284,6 +304,18 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
         t.cache.clear();
         t.rounded.clear();
         std::memcpy(t.x0.data(), x0 + (size_t)k * nx, nx * sizeof(double));
+    }
+    {
+        // Rows nobody references are reclaimed: when every tree is cold (no node carries a row of its own or of its parent)
+        // the pools start from zero again.  Without this a fleet that is reset and solved at every step, never shifted --
+        // the cold searches of fleet.closed_loop_study -- kept every row ever written: 880 k rows of ~8 KB over the
+        // published sd = .01 study, 25-30 GB with the spare pool and the regrow copies (only hmpc_fleet_shift compacted).
+        bool cold = true;
+        for (int k = 0; k < K && cold; k++) {
+            const FleetTree &t = f->trees[k];
+            for (int i = 0; i < t.n && cold; i++) cold = t.row[i] < 0 && t.wrow[i] < 0;
+        }
+        if (cold) f->used = 0;
     }
     std::vector<std::vector<int>> picks(K);
     std::vector<int> order;

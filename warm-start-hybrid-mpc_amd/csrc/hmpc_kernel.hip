@@ -48,6 +48,31 @@
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
 #define HMPC_POLISH_ROUNDS_LAST 10 // the last attempt, on the iterate the solve would return (round 3, with the rule that every row with a negative multiplier leaves)
+#define HMPC_ESC_MAX 2 // tolerance escalations after a failed last attempt (ipm_solve) ...
+#define HMPC_ESC_ITERS 6 // ... and iterations an escalated solve may spend without meeting its tolerance
+// The tolerance escalation is compiled into the run-time-sized kernels only: in the one-wave kernel of the cart-pole
+// shape its two more live values move the register allocation (scratch 124 -> 140 B per lane), and no optimal node of
+// the cart-pole systems has ever reached it (every one polishes: 0 of 165 824 + 40 424 + 21 000 nodes of the parity sweeps).
+// -DHMPC_ESC_ALL compiles it into every kernel (A/B builds).
+#ifdef HMPC_ESC_ALL
+#define HMPC_ESC_ENABLED(D) true
+#else
+#define HMPC_ESC_ENABLED(D) (D::kNX <= 0)
+#endif
+// A/B switches of the round-4 accuracy changes in the compile-time (cart-pole) kernels; the run-time-sized kernels always
+// have them.  Measured on the headline launch (4096 nodes, two runs each, same box; iteration counts and records of the
+// cart-pole nodes identical in all three): both off 8.546 / 8.570 ms, stable denominator 8.559 / 8.585, both 8.654 / 8.658
+// (132 B of scratch instead of 124).  lam_0 from its row stays out of the cart-pole kernels: their D stays orders of
+// magnitude smaller (every optimal node ends at the polish, mu ~ 1e-9), the row's error with it.
+#ifndef HMPC_LAM0_ROW
+#define HMPC_LAM0_ROW 0
+#endif
+#ifndef HMPC_STABLE_DEN
+#define HMPC_STABLE_DEN 1
+#endif
+#ifndef HMPC_NARROW_PANEL // (0: diagnostic builds without the narrow panel of stages whose binaries are all fixed)
+#define HMPC_NARROW_PANEL 1
+#endif
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
@@ -1351,7 +1376,7 @@ template <class D, int MQ> DEV int factor_tiles(const DevProb &p, const Lds &S, 
                 }
             };
             constexpr int NUMC = 8;
-            if (nub > 0 && nuc <= NUMC && __popcll(fm1) == nub) {
+            if (HMPC_NARROW_PANEL && nub > 0 && nuc <= NUMC && __popcll(fm1) == nub) {
                 panel(std::integral_constant<int, NUMC>(), nuc);
                 if (lane < nub) S.dinv[t * nu + nuc + lane] = 1.0; // (the binaries: unit pivots, their multipliers stay zero)
             } else {
@@ -1883,7 +1908,7 @@ DEV void kkt_sweeps_wave(const DevProb &p, const Lds &S, int lane, bool usex0, c
             // (a stage whose binaries are all fixed: their pivots were skipped, their multipliers are zero -- the chain ends
             // with the continuous inputs)
             const ldsd *lr = Lp + jc * nup;
-            const int nsub = (t < 64 && ((S.fullfix >> t) & 1ull)) ? (nuc + 3) / 4 * 4 : nur;
+            const int nsub = (HMPC_NARROW_PANEL && t < 64 && ((S.fullfix >> t) & 1ull)) ? (nuc + 3) / 4 * 4 : nur;
             for (int jj = 0; jj < nsub; jj += 4) {
                 const double c0 = lr[jj], c1 = lr[jj + 1], c2 = lr[jj + 2], c3 = lr[jj + 3];
                 const int s0 = nx + jj;
@@ -2146,6 +2171,17 @@ DEV void kkt_solve(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, in
         }
         dnuf[o] = a;
     }
+    // lam_0 from the stationarity row of x_0 (prescribed: the row defines its multiplier, as for the fixed binaries).
+    // Through the recursion -- lam_0 = -(P_0 x_0 + p_0) above -- it carries the rounding of the cost-to-go of stage 0,
+    // eps |P_0| with |P_0| ~ max D: 2e-6 in that row of the dual residual on deep nodes of BASELINE configs[4] (every other
+    // row: 1e-15), which the refinement -- it takes prescribed components as met -- never saw.  Same as oracle/hsde_qp.c.
+    for (int i = lane; i < nx; i += D::kNT) {
+        double a = own_g ? gs * gsrc[i] : 0.0;
+        for (int j = 0; j < nz; j++) a -= S.P[i * nz + j] * dw[j];
+        a -= ccol_dot<D>(p, S, 0, i, S.e);
+        for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + i] * dlam[nx + l];
+        dlam[i] = a;
+    }
     __syncthreads();
     FSTAMP(10);
 }
@@ -2372,6 +2408,17 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
         }
         dnuf[o] = a;
     }
+    if constexpr (HMPC_LAM0_ROW) { // lam_0 from the stationarity row of x_0 (see kkt_solve)
+        if (lane < NX) {
+            double a = own_g ? gs * gsrc[lane] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NZ; j++) a -= S.P[lane * NZ + j] * dw[j];
+            a -= ccol_dot<D>(p, S, 0, lane, S.e);
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += S.AB[l * NZ + lane] * dlam[NX + l];
+            dlam[lane] = a;
+        }
+    }
     __syncthreads();
     FSTAMP(10);
 }
@@ -2425,6 +2472,23 @@ template <class D> DEV double wPv(const DevProb &p, const Lds &S, int lane, cons
     return acc;
 }
 
+// (s w - v)' P (s w - v) (per-lane partial sum) for a direction v
+template <class D> DEV double dPd(const DevProb &p, const Lds &S, int lane, const ldsd *v, double sc)
+{
+    const int nx = D::nx(p), nz = D::nz(p), T = p.T, n = T * nz + nx;
+    double acc = 0;
+    LANE_OPAQUE(lane);
+    for (int o = lane; o < n; o += D::kNT) {
+        const int t = o / nz < T ? o / nz : T;
+        const int i = o - t * nz, dim = t < T ? nz : nx;
+        const ldsd *PP = t < T ? S.P : S.PT;
+        double a = 0;
+        for (int j = 0; j < dim; j++) a += PP[i * dim + j] * (sc * S.w[t * nz + j] - v[t * nz + j]);
+        acc += a * (sc * S.w[o] - v[o]);
+    }
+    return acc;
+}
+
 // One interior-point solve of the node with / without the terminal-set rows.
 // Returns status; tau and the iteration count through references.
 // WARM: the instantiation that accepts a parent's record (hmpc_warm).  The cold kernels are compiled without any of it:
@@ -2464,6 +2528,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     bool tried = false; // the polish has been tried (and failed) on the current iterate
     int attempts = 0;
     double last_alpha = 0, last_dtau = 0, last_dkap = 0;
+#ifdef HMPC_TRACE_STEP
+    double dbg_den = 0;
+#endif
 #ifdef HMPC_STAMPS
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
     long long facc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -2631,6 +2698,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (trace && lane == 0 && it < 64) {
             double *tr = trace + it * 8;
             tr[0] = tau; tr[1] = kap; tr[2] = mu; tr[3] = rcinf / tau; tr[4] = rdinf / tau; tr[5] = gap; tr[6] = eta; tr[7] = certinf;
+#ifdef HMPC_TRACE_STEP // (diagnostic builds: the step that led here instead of the certificate columns)
+            tr[6] = last_dtau; tr[7] = last_alpha; tr[1] = dbg_den;
+#endif
         }
         // Two levels (as in Ipopt's acceptable / desired tolerances).  ACCEPTABLE: scaled residuals and
         // gap <= tol.  DESIRED: acceptable and gap, dual residual <= 1e-2 tol -- they bound the suboptimality, and
@@ -2640,53 +2710,83 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         // them is worse (precision floor of the linear algebra) it is undone -- the direction is still
         // in place -- and the acceptable iterate returned.
         bool polish = false;
-        {
-            const double gtol = p.tol * (1 + fmin(fabs(pobj), fabs(dob)));
-            const bool acceptable = rcinf / tau <= p.tol * (1 + winf / tau + x0inf) &&
-                                    rdinf / tau <= p.tol * (1 + zinf / tau) && gap <= gtol;
+        // TOLERANCE ESCALATION (round 4; same rule as oracle/hsde_qp.c solve_one).  On relaxations without strict
+        // complementarity (the random MLD of BASELINE configs[4]) the active-set exchange of the polish cycles when the set
+        // is read from an iterate of gap 1e-8, and the iterate such a solve returned instead is ~sqrt(gap) off in the
+        // trajectory.  When the LAST attempt has failed on the iterate the solve would return, the stopping tolerance
+        // drops by 100 (twice at most), the iteration goes on, and the next iterate that meets it gets a last attempt of
+        // its own.  The level lives in `attempts` (ATTEMPTS + 2 esc, + 1 once the level's attempt is spent): no state of
+        // its own in a loop that is short of registers.  A node whose polish verifies never gets here.
+        int action = 0; // 0: go on iterating, 1: leave the loop, 2: undo the last step and leave
+        for (;;) {
+            constexpr int kEscMax = HMPC_ESC_ENABLED(D) ? HMPC_ESC_MAX : 0;
+            const int esc = (kEscMax > 0 && attempts > HMPC_POLISH_ATTEMPTS) ? (attempts - HMPC_POLISH_ATTEMPTS) >> 1 : 0;
+            const double tole = esc == 0 ? p.tol : esc == 1 ? 1e-2 * p.tol : 1e-4 * p.tol;
+            const double gtol0 = p.tol * (1 + fmin(fabs(pobj), fabs(dob))), gtol = tole * (1 + fmin(fabs(pobj), fabs(dob)));
+            const bool acceptable = rcinf / tau <= tole * (1 + winf / tau + x0inf) &&
+                                    rdinf / tau <= tole * (1 + zinf / tau) && gap <= gtol;
+            // (acceptable at the tolerance the caller asked for: what an escalated solve falls back on)
+            const bool acc0 = rcinf / tau <= p.tol * (1 + winf / tau + x0inf) && rdinf / tau <= p.tol * (1 + zinf / tau) && gap <= gtol0;
             // The polish (below) is tried as soon as the iterate is good enough to read the active set from
             // (ptol), once per iterate, and not on an iterate that is about to be undone.
             const double gptol = p.ptol * (1 + fmin(fabs(pobj), fabs(dob)));
             // the barrier parameter is exhausted and the point is optimal to 100 x tol (1e-6, a simplex code's
             // default): nothing more can be gained from the interior-point iteration on an interior-free node
-            const bool exhausted = status != HMPC_OPTIMAL && mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
-                                   rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol;
+            const bool exh0 = mu < 1e-11 && rcinf / tau <= 100 * p.tol * (1 + winf / tau + x0inf) &&
+                              rdinf / tau <= 100 * p.tol * (1 + zinf / tau) && gap <= 100 * gtol0;
+            const bool exhausted = status != HMPC_OPTIMAL && exh0;
+            // an escalated solve that no longer gets closer returns what it has (acceptable to the caller's tolerance)
+            const bool stalled = esc > 0 && status == HMPC_OPTIMAL && !acceptable && (acc0 || exh0) && extra_done >= HMPC_ESC_ITERS;
             // (the iterate this solve would return gets one last attempt even when the regular ones are used up -- they were
             // spent on immature iterates; 5 of 4 000 optimal nodes of the one-wall system at N=40 ended that way)
-            const bool desired = gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * p.tol * (1 + zinf / tau);
-            const bool final_exit = (acceptable && (desired || extra_done >= 3 || it == p.max_iter)) || exhausted;
+            const bool desired = gap <= 1e-2 * gtol && rdinf / tau <= 1e-2 * tole * (1 + zinf / tau);
+            const bool final_exit = (acceptable && (desired || extra_done >= 3 || it == p.max_iter)) || exhausted || stalled;
             polish = p.polish && !tried &&
                      (attempts < HMPC_POLISH_ATTEMPTS
                           ? (acceptable || exhausted || (status != HMPC_OPTIMAL && rcinf / tau <= p.ptol * (1 + winf / tau + x0inf) &&
                                                          rdinf / tau <= p.ptol * (1 + zinf / tau) && gap <= gptol))
-                          : (attempts == HMPC_POLISH_ATTEMPTS && final_exit));
-            if (polish) {
-                // decided by the passes of the polish
-            } else if (acceptable) {
+                          : (((attempts - HMPC_POLISH_ATTEMPTS) & 1) == 0 && final_exit));
+            if (polish) break; // decided by the passes of the polish
+            if (p.polish && tried && attempts > HMPC_POLISH_ATTEMPTS && ((attempts - HMPC_POLISH_ATTEMPTS) & 1) == 1 && final_exit && esc < kEscMax &&
+                it < p.max_iter) {
+                // the last attempt of this level has failed on the iterate the solve would return: next level
+                attempts++;
+                extra_done = 0;
                 status = HMPC_OPTIMAL;
-                if (desired || extra_done >= 3 || it == p.max_iter) break;
-                extra_done++;
+                continue; // (the exits below are decided at the new tolerance)
+            }
+            if (acceptable) {
+                status = HMPC_OPTIMAL;
+                if (desired || extra_done >= 3 || it == p.max_iter) action = 1;
+                else extra_done++;
             } else if (exhausted) {
                 status = HMPC_OPTIMAL;
-                break;
+                action = 1;
             } else if (status == HMPC_OPTIMAL) {
-                for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
-                for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
-                for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
-                ROWS_BEGIN(k, rw)
-                    if (R.D(k, rw.e) != 0.0) {
-                        R.z(k, rw.e) -= last_alpha * R.dz(k, rw.e);
-                        R.s(k, rw.e) -= last_alpha * R.prod(k, rw.e);
-                    }
-                ROWS_END
-                tau -= last_alpha * last_dtau;
-                kap -= last_alpha * last_dkap;
-                __syncthreads();
-                set_prescribed<D>(p, S, lane, tau); // x_0 and the fixed binaries follow tau exactly, also after the way back
-                __syncthreads();
-                break;
+                if (esc > 0 && (acc0 || exh0)) { // on the way to a tighter tolerance
+                    if (extra_done >= HMPC_ESC_ITERS) action = 1;
+                    else extra_done++;
+                } else action = 2;
             }
+            break;
         }
+        if (action == 2) {
+            for (int o = lane; o < n; o += D::kNT) S.w[o] -= last_alpha * S.w2[o];
+            for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] -= last_alpha * S.lam2[o];
+            for (int o = lane; o < T * nub; o += D::kNT) S.nuf[o] -= last_alpha * S.nuf2[o];
+            ROWS_BEGIN(k, rw)
+                if (R.D(k, rw.e) != 0.0) {
+                    R.z(k, rw.e) -= last_alpha * R.dz(k, rw.e);
+                    R.s(k, rw.e) -= last_alpha * R.prod(k, rw.e);
+                }
+            ROWS_END
+            tau -= last_alpha * last_dtau;
+            kap -= last_alpha * last_dkap;
+            __syncthreads();
+            set_prescribed<D>(p, S, lane, tau); // x_0 and the fixed binaries follow tau exactly, also after the way back
+            __syncthreads();
+        }
+        if (action) break;
         // Every infeasibility exit carries a bound on the certificate residual: a ray that is not a proof must
         // not prune a subtree (a node whose tau vanishes without one ends MAXITER / NUMERICAL and is surfaced).
         if (!polish && eta > 0 && (certinf <= p.tol_inf * eta || (tau <= 1e-8 * kap && certinf <= 1e-3 * eta))) {
@@ -2939,16 +3039,35 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         }
         tried = false;
         STAMP(3);
-        double g1 = 0;
-        g1 = wPv<D>(p, S, lane, S.w1);
-        double fyhz1 = lin_obj<D>(p, S, rm, lane, S.lam1, S.nuf1, S.e);
-        {
+        // Denominator of the tau step:  kap/tau + w'Pw/tau^2 - 2 w'P w1/tau - (f'y1 + h'z1).  The constant direction solves
+        // P w1 + E'y1 + C'z1 = 0, E w1 = f, C w1 - z1/D = h, hence -(f'y1 + h'z1) = w1'P w1 + z1'D^-1 z1 and
+        //     den = kap/tau + (w/tau - w1)' P (w/tau - w1) + sum_i z1_i^2 / D_i :
+        // a sum of nonnegative terms.  As the difference of four O(1 .. 100) terms (until round 4) it lost everything in the
+        // last iterations -- the quadratic terms go to zero like kap/tau -- once the constant direction was only good to
+        // 1e-8: on a deep node of BASELINE configs[4] den came out ten times too small at mu = 3e-11, tau fell from 0.20 to
+        // 0.046 in one step and the dual residual rose from 5e-8 to 3e-5 (profiles/r04_den_cancellation.txt).
+        double den;
+        if constexpr (HMPC_STABLE_DEN) {
+            double q1 = dPd<D>(p, S, lane, S.w1, 1.0 / tau), q2 = 0.0;
+            ROWS_BEGIN(k, rw)
+                const double d = R.D(k, rw.e);
+                if (d != 0.0) { const double z1 = S.e[rw.e]; q2 += z1 * z1 * frcp(d); } // (S.e: the constant direction's dz)
+            ROWS_END
+            double v[2] = {q1, q2};
+            const int op[2] = {0, 0};
+            block_reduce<D, 2>(v, op, S.red, lane);
+            den = kap / tau + v[0] + v[1];
+        } else {
+            double g1 = wPv<D>(p, S, lane, S.w1);
+            double fyhz1 = lin_obj<D>(p, S, rm, lane, S.lam1, S.nuf1, S.e);
             double v[2] = {g1, fyhz1};
             const int op[2] = {0, 0};
             block_reduce<D, 2>(v, op, S.red, lane);
-            g1 = v[0] * 2.0 / tau; fyhz1 = v[1];
+            den = kap / tau + wPw / (tau * tau) - v[0] * 2.0 / tau - v[1];
         }
-        const double den = kap / tau + wPw / (tau * tau) - g1 - fyhz1;
+#ifdef HMPC_TRACE_STEP
+        dbg_den = den / (kap / tau);
+#endif
 
         double dtau_a = 0, dkap_a = 0, sigma = 0;
         for (int pass = 0; pass < 2; pass++) {
@@ -3064,6 +3183,44 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 ROWS_BEGIN(k, rw)
                     if (R.D(k, rw.e) != 0.0) R.dz(k, rw.e) += S.e[rw.e];
                 ROWS_END
+            }
+            // Multipliers of the fixed binaries from the step that is ACTUALLY taken (run-time-sized kernels; round 4).  Their
+            // stationarity row defines them, and the refinement above leaves that row alone; but what was accumulated --
+            // nuf2 + dtau nuf1 (+ corrections) -- goes with the multiplier steps as the SOLVES returned them, while the step
+            // uses the constant direction's dz recomputed as D (C w1 - h) (it is not stored): the two differ by the rounding of
+            // D (C w1) against D h, ~eps D, and with D = z / s at 1e9 .. 1e12 in the last iterations the fixed binaries' rows of
+            // the dual residual stood at 1e-7 .. 4e-6 on deep nodes of BASELINE configs[4] (every other row: 1e-13) -- above
+            // the stopping tolerance, so that such nodes left through the exhausted-barrier exit with a gap of 1e-6, or not
+            // at all once the tolerance escalation asked for 1e-10.  (The oracle stores that dz; the cart-pole kernels keep
+            // the accumulated form: their D stays four orders smaller and the row products' registers are spoken for.)
+            if constexpr (D::kNX <= 0) {
+                if (pass == 1) {
+                    __syncthreads();
+                    if (nref > 0) { // (S.e holds the last correction, not the step)
+                        ROWS_BEGIN(k, rw)
+                            S.e[rw.e] = R.D(k, rw.e) != 0.0 ? R.dz(k, rw.e) : 0.0;
+                        ROWS_END
+                        __syncthreads();
+                    }
+                    for (int o = lane; o < T * nub; o += D::kNT) {
+                        if (S.fix[o] >= 0) {
+                            const int t = o / nub, c = nx + nuc + (o - t * nub);
+                            double a = -lin * S.rd[t * nz + c];
+                            for (int j = 0; j < nz; j++) a -= S.P[c * nz + j] * S.w2[t * nz + j];
+                            a -= ccol_dot<D>(p, S, t, c, S.e);
+                            for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + c] * S.lam2[(t + 1) * nx + l];
+                            S.nuf2[o] = a;
+                        }
+                    }
+                    for (int i = lane; i < nx; i += D::kNT) { // (lam_0: the other multiplier a stationarity row defines)
+                        double a = -lin * S.rd[i];
+                        for (int j = 0; j < nz; j++) a -= S.P[i * nz + j] * S.w2[j];
+                        a -= ccol_dot<D>(p, S, 0, i, S.e);
+                        for (int l = 0; l < nx; l++) a += S.AB[l * AB_STRIDE + i] * S.lam2[nx + l];
+                        S.lam2[i] = a;
+                    }
+                    __syncthreads();
+                }
             }
             // slack step from the complementarity row ; step to the boundary
             LANE_OPAQUE(lane);
@@ -3463,6 +3620,21 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     }
 }
 
+// SEPARATE COMPILATION (the shipped build, csrc/Makefile): every instantiation of hmpc_qp_kernel hmpc_pick_kernel can
+// return is compiled in a file of its own (instances/*.hip: HMPC_KERNEL_ONLY + one HMPC_INSTANCE line) -- eight at a time
+// instead of 26 in a row, 5 min -> 1 min --, and the launching translation unit (hmpc_capi.hip, HMPC_EXTERN_INSTANCES)
+// only declares them.  Without HMPC_EXTERN_INSTANCES (the diagnostic builds) they are instantiated where they are used.
+// HMPC_INSTANCE_LIST must name exactly the argument lists of hmpc_pick_kernel below.
+#define HMPC_INSTANCE_LIST(X)                                                                              \
+    X(4, 7, 4, 10, 3, 2, 1) X(4, 7, 4, 5, 2, 1, 2) X(4, 7, 4, 10, 3, 1, 2) X(4, 7, 4, 3, 1, 1, 4) X(4, 7, 4, 5, 2, 1, 4) \
+    X(4, 4, 2, 7, 2, 1, 2) X(4, 4, 2, 4, 1, 1, 4)                                                          \
+    X(-1, 0, 0, 0, 0, 0, 1) X(-1, 0, 0, 0, 0, 0, 2) X(-1, 0, 0, 0, 0, 0, 4) X(0, 0, 0, 0, 0, 0, 1) X(0, 0, 0, 0, 0, 0, 2) X(0, 0, 0, 0, 0, 0, 4)
+#define HMPC_KERNEL_SIG(NX, NU, NUB, F, Bn, Tn, NWv, W) \
+    void hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv, W>(const DevProb, const double *, int, const int8_t *, int, const DevOut, double *, double *, const int32_t *, const DevWarm)
+#define HMPC_INSTANCE(NX, NU, NUB, F, Bn, Tn, NWv) /* one line of an instance file: the cold and the hand-down kernel */ \
+    template __global__ HMPC_KERNEL_SIG(NX, NU, NUB, F, Bn, Tn, NWv, false);                              \
+    template __global__ HMPC_KERNEL_SIG(NX, NU, NUB, F, Bn, Tn, NWv, true);
+#ifndef HMPC_KERNEL_ONLY // (the instance files and the code-generation probes compile hmpc_qp_kernel only)
 // Processing order of a large frontier: counting sort of the nodes by their number of fixed binaries (one workgroup;
 // the order inside a bucket is whatever the atomics give -- a record does not depend on when its node is solved).
 // Launches with hand-down (warm.index set): a node whose PARENT needed the terminal-set rows goes first -- its own solve is
@@ -3527,7 +3699,12 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
     for (int b = threadIdx.x + 8 * 1024; b < B; b += 1024) order[atomicAdd(&bins[bucket(b)], 1)] = b;
 }
 
-#ifndef HMPC_KERNEL_ONLY // (defined by the one-instantiation probe used to inspect the generated code)
+#ifdef HMPC_EXTERN_INSTANCES
+#define HMPC_EXTERN_INSTANCE(NX, NU, NUB, F, Bn, Tn, NWv)                                                  \
+    extern template __global__ HMPC_KERNEL_SIG(NX, NU, NUB, F, Bn, Tn, NWv, false);                       \
+    extern template __global__ HMPC_KERNEL_SIG(NX, NU, NUB, F, Bn, Tn, NWv, true);
+HMPC_INSTANCE_LIST(HMPC_EXTERN_INSTANCE)
+#endif
 // Instantiations: the two cart-pole shapes of the reference (notebooks/cart_pole_with_walls: nx=4,
 // nu=7, 4 binaries; warm_start_hmpc/test/cart_pole_with_wall.py: nx=4, nu=4, 2 binaries), with the
 // row slots of their horizons and 1 / 2 / 4 waves per node, and the generic run-time-sized kernel.

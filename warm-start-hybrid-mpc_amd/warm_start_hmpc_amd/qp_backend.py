@@ -125,8 +125,8 @@ def load_library():
 EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
-                    'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
+                    'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_stop', 'hmpc_fleet_rows', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
+                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_allreduce_incumbent_device', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
 
 
