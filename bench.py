@@ -76,14 +76,29 @@ def cpu_baseline(ctrl, x0, fix):
     one = OracleBatchedQP(ctrl.problem_data(), threads=1)
     sub = fix[:min(256, len(fix))]
     t1 = timed(one, x0, sub)
-    try:  # time the reference's own engine only if it exists on this host
-        import gurobipy  # noqa: F401
-        gurobi = 'importable (not timed: no Gurobi-backed QP path is part of this repository)'
-    except Exception:
-        gurobi = 'unavailable on this host (proprietary, not in the image): the CPU baseline is the oracle port'
-    return {'value': len(fix) / best, 'unit': 'QP subproblems/s', 'cores': cores, 'kind': 'port', 'gurobi': gurobi,
-            'sample': '%d-node frontier of this run, OpenMP over nodes, 3 warm-ups, median of 10 batches (single thread: first %d nodes)' % (len(fix), len(sub)),
-            'single_thread_value': len(sub) / t1}
+    out = {'value': len(fix) / best, 'unit': 'QP subproblems/s', 'cores': cores, 'kind': 'port',
+           'sample': '%d-node frontier of this run, OpenMP over nodes, 3 warm-ups, median of 10 batches (single thread: first %d nodes)' % (len(fix), len(sub)),
+           'single_thread_value': len(sub) / t1}
+    # BASELINE.md section 3 / SURVEY 8d(ii): the reference's own engine beside it, if it exists on this host.  The QP path
+    # over Gurobi is tests/gurobi_reference.py (the model of controller.py:119-184, the optimize / Farkas sequence of
+    # bounded_qp.py:200-228, one node at a time on one thread as the reference); where it runs, IT is the CPU baseline
+    # (kind "gurobi") and the oracle port moves to the key `port`.
+    try:
+        import gurobi_reference
+        if not gurobi_reference.available():
+            raise ImportError('gurobipy')
+        grb = gurobi_reference.GurobiBatchedQP(ctrl.problem_data(), gurobi_params={'Threads': 1})
+        gsub = fix[:min(512, len(fix))]                      # (~0.3 k QP/s published: a bounded sample, 2 - 10 s)
+        grb.solve_batch(x0 if np.ndim(x0) == 1 else x0[:len(gsub)], gsub[:32])
+        r = grb.solve_batch(x0 if np.ndim(x0) == 1 else x0[:len(gsub)], gsub)
+        out = {'value': len(gsub) / r['time'], 'unit': 'QP subproblems/s', 'cores': 1, 'kind': 'gurobi',
+               'sample': 'first %d nodes of the frontier of this run, one Gurobi solve per node on one thread (as the reference), wall time; '
+                         'Gurobi\'s own Runtime: %.0f QP/s' % (len(gsub), len(gsub) / r['solver_time']),
+               'status_equal_to_port': bool(np.array_equal(r['status'], orc.solve_batch(x0 if np.ndim(x0) == 1 else x0[:len(gsub)], gsub)['status'])),
+               'port': out}
+    except Exception as e:
+        out['gurobi'] = 'unavailable on this host (%s): the CPU baseline is the oracle port' % (type(e).__name__ + ': ' + str(e))[:160]
+    return out
 
 
 def shift_bandwidth(ctrl, dev, leaves=65536, trees=64, reps=10):

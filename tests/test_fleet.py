@@ -114,6 +114,36 @@ def test_incumbent_allreduce_through_the_c_abi():
     assert lib.hmpc_comm_destroy(comm) == 0
 
 
+def test_row_pools_of_a_fleet_that_is_never_shifted_stay_bounded():
+    # a fleet that is reset and solved at every step, never shifted -- the cold searches of
+    # fleet.closed_loop_study -- kept every multiplier row ever written (only hmpc_fleet_shift compacted).  Rows nobody
+    # references are reclaimed now: hmpc_fleet_solve starts the pools from zero when every tree is cold; an ended loop
+    # (hmpc_fleet_stop) holds nothing and is not searched.
+    from warm_start_hmpc_amd.fleet import FleetMPC
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    K = 4
+    cold = FleetMPC(ctrl, K)
+    xs = np.repeat(np.array([[0., 0., .5, 0.]]), K, axis=0)
+    used = []
+    for step in range(3):
+        cold.reset()
+        r = cold.solve(xs, 4)
+        used.append(cold.rows()[0])
+    assert used[0] > 0 and max(used[1:]) <= used[0] + 8      # the same searches: the same rows again, not more
+    assert np.all(np.isfinite(r['cost'])) and np.all(r['solves'] > 0)
+    cold.stop(2)                                            # loop 2 has ended
+    for k in (0, 1, 3):
+        cold.reset(k)
+    r = cold.solve(xs, 4)
+    assert r['solves'][2] == 0 and np.isinf(r['cost'][2]) and np.all(r['solves'][[0, 1, 3]] > 0)
+    assert cold.rows()[0] <= used[0]                        # (the stopped loop holds no rows: the pools started from zero again)
+    launched = cold.stats()['launched']
+    for k in (0, 1, 3):
+        cold.stop(k)
+    cold.solve(xs, 4)                                       # nothing is running: nothing is launched
+    assert cold.stats()['launched'] == launched
+
+
 def test_incumbent_exchange_over_rccl_between_two_gpus(tmp_path):
     # Two FRESH processes, one per GPU, communicator from hmpc_comm_unique_id: MIN semantics, the -inf abort path, owner and
     # broadcast of the winning assignment over real RCCL (tests/rccl_two_ranks.py).  Needs two GPUs: on the one-GPU boxes of

@@ -39,6 +39,18 @@ class FleetMPC(object):
     def reset(self, k=-1):
         self.qp._check(self.qp.lib.hmpc_fleet_reset(self._f, int(k)))
 
+    def stop(self, k):
+        """Loop k has ended: its tree is dropped and it takes no part in further steps (no launches, no pool rows) until
+        ``reset`` makes it cold again."""
+        self.qp._check(self.qp.lib.hmpc_fleet_stop(self._f, int(k)))
+
+    def rows(self):
+        """(rows of the multiplier pools in use, rows allocated).  Rows nobody references are reclaimed: ``shift``
+        compacts, and ``solve`` starts the pools from zero when every tree is cold."""
+        used, cap = ctypes.c_int64(), ctypes.c_int64()
+        self.qp._check(self.qp.lib.hmpc_fleet_rows(self._f, ctypes.byref(used), ctypes.byref(cap)))
+        return used.value, cap.value
+
     def solve(self, x0s, frontier_width=8, tol=0., speculation=0):
         """One MIQP per loop from x0s (K, nx), warm-started from the loop's tree.  Returns dict of arrays:
         cost (K,), u0 (K, nu), x1 (K, nx) -- the model's next state --, solves, leaves (K,).
@@ -142,7 +154,12 @@ def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, s
     cold-started search (a second fleet, reset before every step; ``cold_too``) and a warm-started one from the same
     state, their costs compared (the reference's assertion at :171; a disagreement is recorded, not raised), the next
     warm start built from the warm search's leaves (:180-187).  A simulation ends at the step whose MIQP has no solution
-    (:165-166).  ``frontier_width=1`` is the reference's node order.
+    (:165-166).  ``frontier_width=1`` is the reference's node order.  The input applied between two steps is the warm
+    search's u0; the reference takes uc / ub[0] from the COLD solution and x[1] from the warm one (:180-194) -- the same
+    thing wherever the optimum is unique (a tie of the MIQP is the one event in which they can differ: three steps of
+    the published study, tests/test_reference_replay.py).  ``handdown=False`` runs the searches as the reference's published
+    runs did (no parent -> child hand-down: where multipliers are not unique a handed-down solve may return another
+    optimal choice, and solve counts move by a few).
 
     Returns the dictionary of ``BatchedMPC.closed_loop``: per simulation the lists nodes_cs, nodes_ws, len_ws, reopened,
     costs (one entry per step the simulation was alive for; len_ws / reopened / costs only for steps with a solution),
@@ -155,6 +172,7 @@ def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, s
     cold = FleetMPC(controller, K, handdown=handdown) if cold_too else None
     xs = np.repeat(np.asarray(x0, dtype=np.float64)[None], K, axis=0)
     alive = np.ones(K, dtype=bool)
+    stopped = np.zeros(K, dtype=bool)
     st = dict(nodes_ws=[[] for _ in range(K)], nodes_cs=[[] for _ in range(K)], len_ws=[[] for _ in range(K)],
               costs=[[] for _ in range(K)], reopened=[[] for _ in range(K)], cost_mismatches=[])
     steps = 0
@@ -164,8 +182,12 @@ def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, s
             break
         rc = None
         if cold is not None:
-            for k in np.flatnonzero(alive):             # (an ended simulation is not reset: it stays ended)
-                cold.reset(int(k))
+            for k in range(K):                          # (an ended simulation takes no part: no launches, no pool rows)
+                if alive[k]:
+                    cold.reset(k)
+                elif not stopped[k]:
+                    cold.stop(k)
+                    stopped[k] = True
             rc = cold.solve(xs, frontier_width, speculation=speculation)
         rw = warm.solve(xs, frontier_width, speculation=speculation)
         ok = alive & np.isfinite(rw['cost'])

@@ -41,6 +41,9 @@ def main(argv=None, backend_factory=None):
     ap.add_argument('--out', default='.')
     ap.add_argument('--errors', default=None, help='.npz with prescribed model errors (sims, steps, nx)')
     ap.add_argument('--errors-key', default='errors')
+    ap.add_argument('--no-handdown', action='store_true',
+                    help='searches without the parent -> child hand-down of active sets, as in the reference\'s published runs '
+                         '(with it, solve counts move by a few where multipliers are not unique)')
     args = ap.parse_args(argv)
 
     from .mld_system import MLDSystem
@@ -81,7 +84,8 @@ def main(argv=None, backend_factory=None):
         log.write('Error standard deviation {:.3f}\n\n'.format(args.sd))
         if backend_factory is None:                        # the product path: the fleet driver behind the C ABI
             from .fleet import closed_loop_study
-            st = closed_loop_study(ctrl, x0, errors, frontier_width=args.width, cold_too=not args.no_cold, log=log, sim_ids=seeds)
+            st = closed_loop_study(ctrl, x0, errors, frontier_width=args.width, cold_too=not args.no_cold, log=log, sim_ids=seeds,
+                                   handdown=not args.no_handdown)
         else:
             st = BatchedMPC(ctrl).closed_loop(x0, args.steps, seeds=seeds, frontier_width=args.width, cold_too=not args.no_cold,
                                               log=log, errors=errors)
@@ -105,7 +109,7 @@ def main(argv=None, backend_factory=None):
         if rows:
             np.save(os.path.join(args.out, '%s_%s.npy' % (key, tag)), np.array(rows))
     ws = np.array([st['nodes_ws'][k] for k in full]) if full else np.zeros((0, args.steps))
-    print('simulations %d (completed %d), steps %d, sd %.3f' % (args.sims, len(full), st['steps'], args.sd))
+    print('simulations %d (completed %d), steps %d, sd %.3f, hand-down %s' % (args.sims, len(full), st['steps'], args.sd, 'off' if args.no_handdown else 'on'))
     if full:
         print('warm solves/step (steps >= 1): mean %.2f min %d max %d' % (ws[:, 1:].mean(), ws[:, 1:].min(), ws[:, 1:].max()))
         if not args.no_cold:

@@ -93,6 +93,12 @@ def load_library():
         lib.hmpc_fleet_destroy.argtypes = [ctypes.c_void_p]
         lib.hmpc_fleet_reset.restype = ctypes.c_int
         lib.hmpc_fleet_reset.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        lib.hmpc_fleet_stop.restype = ctypes.c_int
+        lib.hmpc_fleet_stop.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+        lib.hmpc_fleet_rows.restype = ctypes.c_int
+        lib.hmpc_fleet_rows.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+        lib.hmpc_allreduce_incumbent_device.restype = ctypes.c_int
+        lib.hmpc_allreduce_incumbent_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         lib.hmpc_fleet_solve.restype = ctypes.c_int
         lib.hmpc_fleet_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double] + [ctypes.c_void_p] * 5
         lib.hmpc_fleet_shift.restype = ctypes.c_int
