@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, 'liboracle_lp.so')
+LIB = os.path.join(HERE, 'liboracle_lp%s.so' % os.environ.get('ORACLE_LIBRARY_SUFFIX', ''))
 _lib = None
 
 

@@ -14,7 +14,7 @@ import time
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, 'liboracle_qp.so')
+LIB = os.path.join(HERE, 'liboracle_qp%s.so' % os.environ.get('ORACLE_LIBRARY_SUFFIX', ''))   # (_asan: the sanitizer build, tests/test_sanitizers.py)
 
 
 def build():

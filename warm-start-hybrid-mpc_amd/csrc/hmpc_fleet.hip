@@ -25,31 +25,7 @@
 #include <unordered_map>
 #include <vector>
 
-struct FleetResult { // a solved node waiting to be consumed by the search (speculative expansion)
-    double obj, nu_lb, nu_ub; // objective; multipliers of the two bounds of the next binary in time
-    int32_t row;              // its row in the pools
-    bool vertex;              // optimal and polished: its record may be handed down to its children (hmpc_warm)
-    bool failed;              // the solver did not converge on it (MAXITER / NUMERICAL): an error IF the search consumes it
-};
-
-struct FleetTree {
-    std::vector<int8_t> fix;   // n x nfix, -1 free / 0 / 1 (chronological prefixes)
-    std::vector<double> lb;    // lower bound, +inf: proved infeasible
-    std::vector<int32_t> row;  // dual row of the current pool the node carries (own if solved, else parent's), -1: none
-    std::vector<int32_t> wrow; // row of the parent's record (primal and dual pools of THIS step) to hand down, -1: none
-    std::vector<uint8_t> alive;
-    std::vector<int16_t> depth; // fixed binaries
-    int n = 0;
-    double ub = std::numeric_limits<double>::infinity();
-    int inc = -1;               // incumbent node
-    int32_t inc_row = -1;       // its row in the primal pool
-    std::vector<double> primal; // its primal row
-    int solves = 0;
-    bool running = true;        // false once the MIQP of a step was infeasible (the loop has ended)
-    std::vector<double> x0;     // state of the last solve
-    std::unordered_map<std::string, FleetResult> cache; // key: the fixed prefix of the identifier
-    std::unordered_map<int32_t, std::vector<int8_t>> rounded; // dive prediction: a solved vertex node's relaxed binaries, rounded, by pool row
-};
+#include "hmpc_tree.h" // FleetResult, FleetTree and the tree bookkeeping (host only, testable under sanitizers)
 
 struct hmpc_fleet {
     hmpc_handle *h = nullptr;
@@ -181,18 +157,6 @@ int fleet_ensure_rows(hmpc_fleet *f, size_t rows)
     return HMPC_OK;
 }
 
-void tree_reset_cold(FleetTree &t, int nfix)
-{
-    t.fix.assign(nfix, (int8_t)-1);
-    t.lb.assign(1, -std::numeric_limits<double>::infinity());
-    t.row.assign(1, -1);
-    t.wrow.assign(1, -1);
-    t.alive.assign(1, 1);
-    t.depth.assign(1, 0);
-    t.n = 1;
-    t.running = true;
-}
-
 } // namespace
 
 extern "C" int hmpc_fleet_create(hmpc_handle *h, int32_t K, hmpc_fleet **out)
@@ -298,13 +262,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
     const int K = f->K, nfix = p.T * p.nub, nx = p.nx, nu = p.nu;
     const int o_lb = (p.T + 1) * nx + (p.T - 1) * p.nc + p.ncL; // nu_lb then nu_ub, contiguous in the dual row
     const double inf = std::numeric_limits<double>::infinity();
-    for (int k = 0; k < K; k++) {
-        FleetTree &t = f->trees[k];
-        t.ub = inf; t.inc = -1; t.inc_row = -1; t.solves = 0;
-        t.cache.clear();
-        t.rounded.clear();
-        std::memcpy(t.x0.data(), x0 + (size_t)k * nx, nx * sizeof(double));
-    }
+    for (int k = 0; k < K; k++) tree_begin_step(f->trees[k], x0 + (size_t)k * nx, nx);
     {
         // Rows nobody references are reclaimed: when every tree is cold (no node carries a row of its own or of its parent)
         // the pools start from zero again.  Without this a fleet that is reset and solved at every step, never shifted --
@@ -322,23 +280,14 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
     struct Launch { int k, depth; };
     std::vector<Launch> launch;
     std::vector<int8_t> level, next; // identifiers of one level of a speculative expansion
-    auto key_of = [&](const int8_t *fx, int depth) { return std::string((const char *)fx, (size_t)depth); };
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (;;) {
         // candidates of every tree: alive, bound below the incumbent; the `width` smallest bounds, first wins ties
         double t0 = now();
         size_t npick = 0;
         for (int k = 0; k < K; k++) {
-            FleetTree &t = f->trees[k];
-            picks[k].clear();
-            if (!t.running) continue;
-            order.clear();
-            for (int i = 0; i < t.n; i++)
-                if (t.alive[i] && t.lb[i] < t.ub - tol) order.push_back(i);
-            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t.lb[a] < t.lb[b]; });
-            if ((int)order.size() > width) order.resize(width);
-            picks[k] = order;
-            npick += order.size();
+            tree_select(f->trees[k], width, tol, picks[k]);
+            npick += picks[k].size();
         }
         f->t_select += now() - t0;
         if (npick == 0) break;
@@ -357,58 +306,17 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             size_t b = 0;
             for (int k = 0; k < K; k++) {
                 FleetTree &t = f->trees[k];
-                for (int i : picks[k]) {
-                    const int8_t *fx = t.fix.data() + (size_t)i * nfix;
-                    if (t.cache.count(key_of(fx, t.depth[i]))) continue;
-                    level.assign(fx, fx + nfix);
-                    int depth = t.depth[i];
-                    for (int s = 0; s <= speculation; s++) {
-                        const size_t cnt = level.size() / nfix;
-                        next.clear();
-                        for (size_t q = 0; q < cnt; q++) {
-                            const int8_t *row = level.data() + q * nfix;
-                            if (s == 0 || !t.cache.count(key_of(row, depth))) {
-                                if (pass == 1) {
-                                    std::memcpy(f->h_fix + b * nfix, row, nfix);
-                                    std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
-                                    // hand-down: the picked node receives its parent's record (solved in an earlier
-                                    // round of this step); a speculative descendant's parent rides in this very launch
-                                    f->h_widx[b] = (s == 0 && f->handdown) ? t.wrow[i] : -1;
-                                    any_warm |= f->h_widx[b] >= 0;
-                                    launch.push_back({k, depth});
-                                }
-                                b++;
-                            }
-                            if (s < speculation && depth < nfix)
-                                for (int v = 0; v < 2; v++) {
-                                    next.insert(next.end(), row, row + nfix);
-                                    next[next.size() - nfix + depth] = (int8_t)v;
-                                }
+                for (int i : picks[k])
+                    tree_expand(t, i, nfix, speculation, dive, f->handdown != 0, level, next, [&](const int8_t *row, int depth, int32_t widx) {
+                        if (pass == 1) {
+                            std::memcpy(f->h_fix + b * nfix, row, nfix);
+                            std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
+                            f->h_widx[b] = widx;
+                            any_warm |= widx >= 0;
+                            launch.push_back({k, depth});
                         }
-                        if (next.empty()) break;
-                        level.swap(next);
-                        depth++;
-                    }
-                    if (dive && t.wrow[i] >= 0) {
-                        auto pr = t.rounded.find(t.wrow[i]);
-                        if (pr != t.rounded.end()) {
-                            level.assign(fx, fx + nfix); // the predicted path, one binary more per step
-                            for (int j = t.depth[i]; j < nfix; j++) {
-                                for (int side = 0; side < 2; side++) { // the sibling of the step, then the step itself
-                                    level[j] = side == 0 ? (int8_t)(1 - pr->second[j]) : pr->second[j];
-                                    if (t.cache.count(key_of(level.data(), j + 1))) continue;
-                                    if (pass == 1) {
-                                        std::memcpy(f->h_fix + b * nfix, level.data(), nfix);
-                                        std::memcpy(f->h_x0 + b * nx, t.x0.data(), nx * sizeof(double));
-                                        f->h_widx[b] = -1; // (its parent rides in this very launch)
-                                        launch.push_back({k, j + 1});
-                                    }
-                                    b++;
-                                }
-                            }
-                        }
-                    }
-                }
+                        b++;
+                    });
             }
             B = b;
         }
@@ -462,49 +370,16 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                     for (int j = 0; j < nfix; j++) bits[j] = u[(j / p.nub) * nu + p.nuc + (j % p.nub)] > 0.5 ? 1 : 0;
                     f->trees[launch[q].k].rounded.emplace(e.row, std::move(bits));
                 }
-                f->trees[launch[q].k].cache.emplace(key_of(f->h_fix + q * nfix, d), e);
+                f->trees[launch[q].k].cache.emplace(tree_key(f->h_fix + q * nfix, d), e);
             }
             f->used += B;
         }
         // prune / incumbent / branch, node by node in selection order (branch_and_bound.py:476-489)
         struct Tick { double &acc; double t0; ~Tick() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; } } tick{f->t_consume, t0};
         for (int k = 0; k < K; k++) {
-            FleetTree &t = f->trees[k];
-            for (int i : picks[k]) {
-                auto it = t.cache.find(key_of(t.fix.data() + (size_t)i * nfix, t.depth[i]));
-                if (it == t.cache.end()) return fail(HMPC_EDEVICE, "fleet: a selected node has no result");
-                const FleetResult e = it->second;
-                t.cache.erase(it);
-                // (a speculative descendant that did not converge is an error only here, when the search gets to it: the
-                // result of a step does not depend on what rode along)
-                if (e.failed) return fleet_fail(f, HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
-                const double obj = e.obj;
-                t.solves++;
-                t.lb[i] = obj;
-                t.row[i] = e.row;
-                const double cutoff = t.ub - tol;
-                if (obj >= cutoff) continue;
-                const int d = t.depth[i];
-                if (d == nfix) { // every binary fixed: new incumbent
-                    t.ub = obj;
-                    t.inc = i;
-                    t.inc_row = e.row; // (its primal row is fetched once, at the end of the step, with the others')
-                } else { // branch on the next binary in time; child bound = parent bound + multiplier of the tightened bound
-                    for (int v = 0; v < 2; v++) {
-                        const size_t c = t.n;
-                        t.fix.resize((c + 1) * nfix);
-                        std::memcpy(t.fix.data() + c * nfix, t.fix.data() + (size_t)i * nfix, nfix);
-                        t.fix[c * nfix + d] = (int8_t)v;
-                        t.lb.push_back(obj + (v == 1 ? e.nu_lb : e.nu_ub));
-                        t.row.push_back(e.row);
-                        t.wrow.push_back(e.vertex ? e.row : -1);
-                        t.alive.push_back(1);
-                        t.depth.push_back((int16_t)(d + 1));
-                        t.n++;
-                    }
-                    t.alive[i] = 0;
-                }
-            }
+            const int bad = tree_consume(f->trees[k], picks[k], nfix, tol);
+            if (bad == 1) return fail(HMPC_EDEVICE, "fleet: a selected node has no result");
+            if (bad == 2) return fleet_fail(f, HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
         }
     }
     {   // the incumbents' primal rows: one gather launch, one copy
@@ -528,11 +403,7 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
         t.cache.clear();
         if (cost) cost[k] = t.running ? t.ub : inf;
         if (solves) solves[k] = t.solves;
-        if (n_leaves) {
-            int c = 0;
-            for (int i = 0; i < t.n; i++) c += t.alive[i];
-            n_leaves[k] = t.running ? c : 0;
-        }
+        if (n_leaves) n_leaves[k] = t.running ? tree_leaves(t) : 0;
         const bool ok = t.running && t.inc >= 0;
         for (int j = 0; j < nu && u0; j++) u0[(size_t)k * nu + j] = ok ? t.primal[(size_t)(p.T + 1) * nx + j] : NAN;
         for (int j = 0; j < nx && x1; j++) x1[(size_t)k * nx + j] = ok ? t.primal[nx + j] : NAN;
@@ -564,16 +435,7 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
         if (cover) cover[k] = 0;
         if (reopened) reopened[k] = 0;
         if (!t.running || t.inc < 0) continue;
-        const double *u = t.primal.data() + (size_t)(p.T + 1) * nx;
-        for (int i = 0; i < t.n; i++) {
-            if (!t.alive[i]) continue;
-            bool agree = true;
-            for (int q = 0; q < nub && agree; q++) {
-                const int fq = t.fix[(size_t)i * nfix + q];
-                agree = fq < 0 || fq == (int)std::rint(u[nuc + q]);
-            }
-            if (agree) keep[k].push_back(i);
-        }
+        tree_retain(t, t.primal.data() + (size_t)(p.T + 1) * nx, nuc, nub, nfix, keep[k]);
         B += keep[k].size();
     }
     if (B == 0) { guard.ok = true; return HMPC_OK; }
@@ -612,33 +474,14 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
     HIPCHK(hipStreamSynchronize(f->stream));
     // the shifted leaves are the next tree: identifiers move one stage towards the present
     b = 0;
-    std::vector<int8_t> nfixv;
     for (int k = 0; k < K; k++) {
         FleetTree &t = f->trees[k];
         if (keep[k].empty()) continue;
         const size_t n = keep[k].size();
-        nfixv.assign(n * nfix, (int8_t)-1);
-        std::vector<double> lb(n);
-        std::vector<int32_t> row(n);
-        std::vector<int16_t> depth(n);
-        int reop = 0;
-        for (size_t j = 0; j < n; j++, b++) {
-            const int i = keep[k][j];
-            if (!(f->h_flags[b] & 1)) return fail(HMPC_EDEVICE, "fleet: host and device disagree on the retain rule");
-            std::memcpy(nfixv.data() + j * nfix, t.fix.data() + (size_t)i * nfix + nub, nfix - nub);
-            lb[j] = f->h_lb[b];
-            const bool re = (f->h_flags[b] & 2) != 0;
-            reop += re;
-            row[j] = (int32_t)b; // (a reopened leaf carries its row too: it is re-solved before anything reads it)
-            depth[j] = (int16_t)std::max(0, (int)t.depth[i] - nub);
-        }
-        t.fix = nfixv;
-        t.lb = lb;
-        t.row = row;
-        t.wrow.assign(n, -1); // (the records of the step that ends here are not handed down across the shift)
-        t.depth = depth;
-        t.alive.assign(n, 1);
-        t.n = (int)n;
+        for (size_t j = 0; j < n; j++)
+            if (!(f->h_flags[b + j] & 1)) return fail(HMPC_EDEVICE, "fleet: host and device disagree on the retain rule");
+        const int reop = tree_adopt_shifted(t, keep[k], f->h_lb + b, f->h_flags + b, (int32_t)b, nub, nfix);
+        b += n;
         if (cover) cover[k] = (int32_t)n;
         if (reopened) reopened[k] = reop;
     }
