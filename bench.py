@@ -237,13 +237,38 @@ def other_configs(dev):
     from warm_start_hmpc_amd.qp_backend import HipBatchedQP
     out = {}
     c40 = make_controller('cart_pole_with_walls', T=40, backend='hip')
-    for name, f in (('cart_pole_N40_random_prefix_p0.1_2048', random_prefix_frontier(40, 4, 2048, p_one=0.1)),
-                    ('cart_pole_N40_random_prefix_p0.5_2048', random_prefix_frontier(40, 4, 2048, p_one=0.5))):
-        r, _ = _device_rate(c40.qp, np.array([0., 0., 1., 0.]), f, dev)
+    # configs[3]: the replay frontier of ITS OWN tree (320 solved nodes + 161 leaves from x0 = [0, 0, 1, 0]),
+    # tiled to 2048 -- what a search at N = 40 solves; the random-prefix frontiers (95 - 99 % infeasible) stay as secondary keys
+    x40, f40, _ = real_tree_frontier(c40, 2048, 0, None, spread=0.)
+    for name, x, f in (('cart_pole_N40_replay_frontier_2048', x40, f40),
+                       ('cart_pole_N40_random_prefix_p0.1_2048', np.array([0., 0., 1., 0.]), random_prefix_frontier(40, 4, 2048, p_one=0.1)),
+                       ('cart_pole_N40_random_prefix_p0.5_2048', np.array([0., 0., 1., 0.]), random_prefix_frontier(40, 4, 2048, p_one=0.5))):
+        r, _ = _device_rate(c40.qp, x, f, dev)
         r['algorithmic_bytes_per_qp'] = c40.layout.bytes_per_qp()
         r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
         r['kernel'] = 'hmpc_qp_kernel<4,7,4,...> (static row map, %d bytes of LDS per node)' % r['lds_bytes_per_wg']
         out[name] = r
+    # a shape without a built-in instantiation: the register kernel compiled for it at hmpc_create (csrc/hmpc_jit.h)
+    # against the run-time-sized kernel that served such shapes until round 4 (HMPC_JIT=0), same 2048-node frontier
+    try:
+        mldj, objj, x0j = random_mld(nx=6, nuc=2, nub=3, seed=3)
+        Tj = 12
+        cj = HybridModelPredictiveController(mldj, Tj, objj, None, backend=_NoBackend())
+        fj = random_prefix_frontier(Tj, 3, 2048, p_one=0.3)
+        fj[0, :] = -1
+        spec = HipBatchedQP(cj.problem_data())
+        os.environ['HMPC_JIT'] = '0'
+        try:
+            gen = HipBatchedQP(cj.problem_data())
+        finally:
+            del os.environ['HMPC_JIT']
+        rs, _ = _device_rate(spec, x0j, fj, dev)
+        rg, _ = _device_rate(gen, x0j, fj, dev)
+        out['generic_vs_specialised'] = {'system': 'random MLD nx=6 nu=2+3 N=12, 2048 random prefixes (p_one 0.3)', 'kernel_kinds_specialised': list(spec.kernel_info()),
+                                         'kernel_kinds_generic': list(gen.kernel_info()), 'specialised': rs, 'generic': rg,
+                                         'speedup': rs['qp_per_s'] / rg['qp_per_s'], 'statuses_equal': rs['optimal'] == rg['optimal'] and rs['infeasible'] == rg['infeasible']}
+    except Exception as e:
+        out['generic_vs_specialised'] = {'error': repr(e)}
     # configs[4]: frontier = prefixes of a dive to a feasible leaf, every other one with a flipped binary (random
     # prefixes are all infeasible for this generator), tiled
     mld, objective, x0 = random_mld()

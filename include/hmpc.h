@@ -290,6 +290,19 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
                         const double *b, int32_t b_stride, const int32_t *relax, int32_t B, double tol, int32_t max_iter,
                         double *obj, double *x, double *z, int32_t *status, int32_t *iters);
 
+/* Register kernels for any admissible shape.  hmpc_create compiles the fast kernel (static row map: rows and recursions in
+ * registers) for a problem whose shape has no built-in instantiation -- the reference takes any MLDSystem,
+ * warm_start_hmpc/controller.py:58-117 -- from the sources next to the library, with the offline compiler, into an on-disk
+ * cache (csrc/hmpc_jit.h: requirements, environment HMPC_JIT / HMPC_JIT_CACHE / HMPC_HIPCC); shapes outside the static row
+ * map's reach, or hosts without a compiler, are served by the run-time-sized kernel.
+ *   hmpc_kernel_info : which kernel serves the problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming
+ *                      form, 2 built-in register kernel, 3 register kernel compiled for this shape.
+ *   hmpc_jit_build   : the same compilation ahead of time, without a GPU (kf / kb / kt: row slots of [F G] rows, bound rows
+ *                      and terminal rows per lane, ceil(T / floor(64 nw / nc)), ceil(T / floor(64 nw / (2 nub))), max(1,
+ *                      ceil(nT / (64 nw))); kc: longest column of the stage rows, rounded up to even). */
+int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3);
+int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len);
+
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);
 

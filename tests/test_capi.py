@@ -120,3 +120,28 @@ def test_headline_kernel_keeps_its_register_budget(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
     assert scratch and max(scratch) == 0, scratch
+
+
+def test_register_kernel_is_compiled_for_an_arbitrary_shape():
+    # The reference takes any MLDSystem (warm_start_hmpc/controller.py:58-117); the fast kernel here is a compile-time
+    # instantiation.  For a shape without a built-in one hmpc_create compiles it from the same source into an on-disk
+    # cache (csrc/hmpc_jit.h); hmpc_jit_build does the same without a GPU.  A random MLD with nx = 6, nu = 2 + 3 -- three
+    # binaries: their six bound rows do not tile a wavefront --: three shared objects (1 / 2 / 4 waves per node), each
+    # exporting the getter of its two kernels; a second call is a cache hit.
+    import time
+    from helpers import random_mld, _NoBackend
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import jit_shapes, jit_prebuild
+    mld, objective, x0 = random_mld(nx=6, nuc=2, nub=3, seed=3)
+    ctrl = HybridModelPredictiveController(mld, 8, objective, None, backend=_NoBackend())
+    shapes = jit_shapes(ctrl.problem_data())
+    assert [s[:3] + s[6:] for s in shapes] == [(6, 5, 3, 1, 8), (6, 5, 3, 2, 8), (6, 5, 3, 4, 8)]
+    paths = jit_prebuild(ctrl.problem_data())
+    assert len(paths) == 3 and all(os.path.exists(p) for p in paths)
+    for p in paths:
+        assert hasattr(ctypes.CDLL(p), 'hmpc_jit_kernels')
+    tic = time.perf_counter()
+    assert jit_prebuild(ctrl.problem_data()) == paths and time.perf_counter() - tic < 2.0      # (cache hits)
+    # shapes the static row map does not hold, and the built-in ones, are not compiled
+    big = HybridModelPredictiveController(random_mld()[0], 30, random_mld()[1], None, backend=_NoBackend())
+    assert jit_shapes(big.problem_data()) == []

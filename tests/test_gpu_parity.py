@@ -360,6 +360,51 @@ def test_other_problem_shapes_and_size_limit():
     _compare(ctrl, hip.solve_batch(x0, fix), orc.solve_batch(x0, fix), 8, fix, min_polished=0.99, x0=x0)
 
 
+def test_register_kernel_compiled_for_an_arbitrary_shape():
+    # a shape without a built-in instantiation gets the register kernel, compiled at hmpc_create (csrc/hmpc_jit.h): same
+    # results as the oracle at the one tolerance (and as the run-time-sized kernel, which served such shapes until round 4)
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    for (nx, nuc, nub, T, seed) in ((6, 2, 3, 8, 3), (8, 3, 4, 10, 2)):
+        mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
+        ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+        hip, orc = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=8)
+        assert hip.kernel_info() == (3, 3, 3), hip.kernel_info()
+        Cj = np.array([mld.F[2 * nx + 2 * nuc + 4 * j] for j in range(nub)])
+        leaf = np.full((1, T * nub), -1, np.int8)
+        for t in range(T):
+            r = orc.solve_batch(x0, leaf)
+            leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+        rng = np.random.default_rng(seed)
+        fix = np.concatenate((random_prefix_frontier(T, nub, 64, p_one=0.3), np.full((96, T * nub), -1, np.int8)))
+        for k in range(65, 160):
+            d = int(rng.integers(1, T * nub + 1))
+            fix[k, :d] = leaf[0, :d]
+            if k % 2 == 0:
+                j = int(rng.integers(0, d))
+                fix[k, j] = 1 - fix[k, j]
+        for waves in ('1', '2', '4'):
+            os.environ['HMPC_WAVES'] = waves
+            try:
+                a = hip.solve_batch(x0, fix)
+            finally:
+                del os.environ['HMPC_WAVES']
+            b = orc.solve_batch(x0, fix)
+            assert (a['status'] == 0).sum() >= 20 and (a['status'] == 1).sum() >= 20
+            _compare(ctrl, a, b, T, fix, min_polished=0.99, x0=x0, efloor=1e-5)
+        os.environ['HMPC_JIT'] = '0'
+        try:
+            gen = HipBatchedQP(ctrl.problem_data())
+        finally:
+            del os.environ['HMPC_JIT']
+        assert gen.kernel_info() == (0, 0, 0)
+        g = gen.solve_batch(x0, fix)
+        assert np.array_equal(g['status'], a['status'])
+        fin = a['status'] == 0
+        np.testing.assert_allclose(g['obj'][fin], a['obj'][fin], rtol=1e-8, atol=1e-11)
+
+
 def test_streaming_kernel_baseline_config4():
     # BASELINE.json configs[4] (random MLD nx=20, nu=6+8, N=30; rows as in SURVEY 8(d) C4): lists and
     # Riccati factor do not fit one CU's LDS, the generic kernel's streaming form keeps them in global memory

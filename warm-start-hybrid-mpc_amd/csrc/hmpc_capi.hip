@@ -17,6 +17,7 @@
 #include "hmpc_device.h"
 
 #include "hmpc_kernel.hip" // one translation unit: the kernels are launched from this file
+#include "hmpc_jit.h"      // register kernels for shapes without a built-in instantiation, compiled at hmpc_create
 #include "hmpc_shift.hip"
 
 static thread_local std::string g_err;
@@ -56,6 +57,8 @@ struct hmpc_handle {
     void *h_stage = nullptr; // its pinned host mirror
     int staged = 0;
     bool staged_warm = false; // the blocks have room for one handed-down parent record per node
+    std::vector<void *> jit_libs; // shared objects of kernels compiled for this problem's shape (hmpc_jit.h); never unloaded
+    int jit_kernels = 0;          //   how many of the three wave counts run on such a kernel (hmpc_kernel_info)
 };
 
 namespace {
@@ -148,9 +151,64 @@ int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
     return HMPC_OK;
 }
 
+// Register kernels of this problem's shape for 1 / 2 / 4 waves per node, compiled or fetched from the cache (hmpc_jit.h).
+// Shapes with a built-in instantiation, shapes the static row map does not hold, and hosts without a compiler leave jit
+// empty: hmpc_pick_kernel then takes what it always took.
+void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu)
+{
+    if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return;
+    if ((p.nx == 4 && p.nu == 7 && p.nub == 4) || (p.nx == 4 && p.nu == 4 && p.nub == 2)) return; // (built in)
+    if (!p.static_rows || p.nz > 16 || p.nub < 1) return;
+    const int kc = std::max(2, (p.kcol + 1) / 2 * 2);
+    if (kc > HMPC_KC_STRIDE || hmpc_lds_bytes(p, kc, 0) > lds_cu) return;
+    hmpc_jit_shape shapes[3];
+    int slot[3], count = 0;
+    for (int c = 0; c < 3; c++) {
+        int kf = 0, kb = 0, kt = 0;
+        if (!hmpc_static_slots(p, 1 << c, kf, kb, kt)) continue;
+        if (kt < 1) kt = 1;                 // (the row map keeps a terminal slot; a problem without terminal set leaves it empty)
+        if (kf + kb + kt > 16) continue;    // (row state in registers: 4 doubles per slot and lane)
+        shapes[count] = {p.nx, p.nu, p.nub, kf, kb, kt, 1 << c, kc};
+        slot[count++] = c;
+    }
+    if (!count) return;
+    std::vector<std::string> paths;
+    std::string err;
+    (void)hmpc_jit_build_all(shapes, count, paths, err);
+    for (int i = 0; i < count; i++) {
+        if (paths[i].empty()) continue;
+        void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = std::string("dlopen: ") + dlerror(); continue; }
+        auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
+        if (!get) { err = "hmpc_jit_kernels not found in " + paths[i]; continue; }
+        void *cold = nullptr, *warm = nullptr;
+        get(&cold, &warm);
+        libs.push_back(lib);
+        jit[slot[i]] = {(hmpc_kernel_t)cold, (hmpc_kernel_t)warm, shapes[i].nw, kc, 0};
+    }
+    if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: register kernel for this shape not available (%s): the run-time-sized kernel serves it\n", err.c_str());
+}
+
 } // namespace
 
 extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
+
+// Compiles (or finds in the cache) the register kernel of one shape without touching a GPU: what hmpc_create does for a
+// shape without a built-in instantiation, callable ahead of time (packaging, warming the cache of a machine without a
+// compiler from one that has it).  path: where the shared object lies (may be NULL).
+extern "C" int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len)
+{
+    g_err.clear();
+    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 16 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || (nw != 1 && nw != 2 && nw != 4) || kc < 2 ||
+        kc > HMPC_KC_STRIDE || (kc & 1))
+        return fail(HMPC_EINVAL, "jit: not a shape of the static row map");
+    hmpc_jit_shape s{nx, nu, nub, kf, kb, kt, nw, kc};
+    std::vector<std::string> paths;
+    std::string err;
+    if (!hmpc_jit_build_all(&s, 1, paths, err) || paths[0].empty()) return fail(HMPC_EDEVICE, "jit: " + err);
+    if (path && path_len > 0) snprintf(path, (size_t)path_len, "%s", paths[0].c_str());
+    return HMPC_OK;
+}
 
 extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out)
 {
@@ -278,7 +336,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
             gptr2.push_back((int)grow2.size());
         }
         ei.swap(ei2); ej.swap(ej2); reg.gptr.swap(gptr2); reg.grow.swap(grow2); reg.gval.swap(gval2);
-        if (p.ngram > 64) p.static_rows = 0;
+        if (p.ngram > 128) p.static_rows = 0; // (the shipped kernels take 64, hmpc_pick_kernel; kernels compiled for a shape two trips of 64)
     }
 
     auto vec = [](const double *a, size_t n) { return std::vector<double>(a, a + n); };
@@ -370,11 +428,14 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         const int r = atoi(e);
         if (r >= 1 && r <= 2) p.ring = r;
     }
+    // shapes without a built-in instantiation: the register kernel is compiled now (or found in the cache), hmpc_jit.h
+    hmpc_kernel_choice jit[3] = {};
+    hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu);
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
     for (int c = 0; c < 3; c++) {
         hmpc_cfg &cf = h->cfg[c];
-        cf.k = hmpc_pick_kernel(p, 1 << c);
+        cf.k = hmpc_pick_kernel(p, 1 << c, jit);
         cf.lds = hmpc_lds_bytes(p, cf.k.kc, cf.k.big);
         if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
             char msg[256];
@@ -394,6 +455,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         if (cf.max_grid > h->max_grid) h->max_grid = cf.max_grid;
     }
     h->lds = h->cfg[0].lds;
+    for (int c = 0; c < 3; c++) h->jit_kernels += jit[c].fn != nullptr && h->cfg[c].k.fn == jit[c].fn;
     p.fac_ws = nullptr;
     p.fac_stride = 0;
     if (h->cfg[0].k.big || h->cfg[1].k.big || h->cfg[2].k.big) {
@@ -435,6 +497,25 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->d_x0) (void)hipFree(h->d_x0);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
     delete h;
+    return HMPC_OK;
+}
+
+// Which kind of kernel serves this problem, per waves per node (1, 2, 4): 0 run-time-sized, 1 its streaming form,
+// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create.
+extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
+{
+    if (!h || !kind3) return fail(HMPC_EINVAL, "null argument");
+    for (int c = 0; c < 3; c++) {
+        const hmpc_kernel_choice &k = h->cfg[c].k;
+        bool jitted = false;
+        for (void *lib : h->jit_libs) {
+            auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
+            void *a = nullptr, *b = nullptr;
+            if (get) get(&a, &b);
+            jitted |= a == (void *)k.fn;
+        }
+        kind3[c] = k.kc > 0 ? (jitted ? 3 : 2) : k.big ? 1 : 0;
+    }
     return HMPC_OK;
 }
 

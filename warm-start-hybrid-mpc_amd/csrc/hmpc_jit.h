@@ -1,0 +1,189 @@
+// hmpc_jit.h -- register kernels for ANY admissible MLD shape, compiled when a problem is created (host code only).
+//
+// The reference accepts any MLDSystem at one speed (warm_start_hmpc/controller.py:58-117).  Here the fast kernel --
+// hmpc_qp_kernel<NX, NU, NUB, KF, KB, KT, NW> with the static row map: rows in registers, recursions in registers of wave
+// 0 -- is a compile-time instantiation; the library ships the two cart-pole shapes of the reference.  For every other
+// shape that meets the static row map's requirements (nx + nu <= 16; every [F G] row with at most two input coefficients;
+// columns of at most 16 entries; at most 64 Gram entries with terms; at least one binary -- DevProb::static_rows,
+// hmpc_pick_kernel) hmpc_create compiles the instantiation FROM THE SAME SOURCE with the toolchain the library was built
+// with: one small translation unit per number of waves per node,
+//
+//     #define HMPC_KERNEL_ONLY
+//     #define HMPC_JIT_KC <longest column, even>
+//     #include "hmpc_kernel.hip"
+//     HMPC_INSTANCE(NX, NU, NUB, KF, KB, KT, NW)
+//     extern "C" void hmpc_jit_kernels(void **cold, void **warm) { ... }
+//
+// built by hipcc into a shared object in an on-disk cache (HMPC_JIT_CACHE, default <library directory>/jit_cache, else
+// ~/.cache/hmpc_amd), keyed by the shape and a hash of the kernel sources, and loaded with dlopen: the kernel's host stub
+// registers with the HIP runtime like any other translation unit's and is launched through the same function-pointer
+// type.  First use of a shape costs one compilation (~20 s, the three wave counts in parallel), later uses a dlopen.
+// Without a compiler at run time (HMPC_HIPCC, default /opt/rocm/bin/hipcc), without the sources next to the library, or
+// with HMPC_JIT=0, the run-time-sized kernel serves the shape as before (2.7x slower on the cart-pole system).
+// hipRTC was considered: it has no C++ standard headers (<type_traits>, <math.h> of the kernel source) and needs the module
+// launch API; the offline compiler needs neither and is the compiler the shipped kernels were built with.
+#ifndef HMPC_JIT_H
+#define HMPC_JIT_H
+
+#include <dlfcn.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+extern char **environ;
+
+struct hmpc_jit_shape { int nx, nu, nub, kf, kb, kt, nw, kc; };
+
+namespace hmpc_jit {
+
+inline std::string dir_of_library()
+{
+    Dl_info info;
+    static int anchor;
+    if (!dladdr((void *)&anchor, &info) || !info.dli_fname) return ".";
+    std::string p = info.dli_fname;
+    const size_t s = p.rfind('/');
+    return s == std::string::npos ? "." : p.substr(0, s);
+}
+
+inline bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+
+inline bool writable_dir(const std::string &d)
+{
+    if (d.empty()) return false;
+    (void)mkdir(d.c_str(), 0755);
+    return access(d.c_str(), W_OK | X_OK) == 0;
+}
+
+inline std::string source_dir()
+{
+    if (const char *e = getenv("HMPC_JIT_SOURCES")) return e;
+    return dir_of_library() + "/csrc";
+}
+
+inline std::string include_dir()
+{
+    if (const char *e = getenv("HMPC_JIT_INCLUDE")) return e;
+    return dir_of_library() + "/../include";
+}
+
+inline std::string cache_dir()
+{
+    if (const char *e = getenv("HMPC_JIT_CACHE")) { if (writable_dir(e)) return e; }
+    std::string d = dir_of_library() + "/jit_cache";
+    if (writable_dir(d)) return d;
+    if (const char *h = getenv("HOME")) {
+        (void)mkdir((std::string(h) + "/.cache").c_str(), 0755);
+        d = std::string(h) + "/.cache/hmpc_amd";
+        if (writable_dir(d)) return d;
+    }
+    d = "/tmp/hmpc_amd_jit";
+    return writable_dir(d) ? d : std::string();
+}
+
+// FNV-1a over the sources a kernel is compiled from: an edit of any of them is another cache entry
+inline uint64_t source_hash()
+{
+    uint64_t hsh = 1469598103934665603ull;
+    for (const std::string &f : {source_dir() + "/hmpc_kernel.hip", source_dir() + "/hmpc_device.h", include_dir() + "/hmpc.h"}) {
+        std::ifstream in(f, std::ios::binary);
+        char buf[4096];
+        while (in) {
+            in.read(buf, sizeof buf);
+            for (std::streamsize i = 0; i < in.gcount(); i++) { hsh ^= (unsigned char)buf[i]; hsh *= 1099511628211ull; }
+        }
+    }
+    return hsh;
+}
+
+inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
+{
+    char b[160];
+    snprintf(b, sizeof b, "hmpc_k_%d_%d_%d_%d_%d_%d_w%d_kc%d_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, (unsigned long long)hsh);
+    return b;
+}
+
+inline std::string compiler() { const char *e = getenv("HMPC_HIPCC"); return e ? e : "/opt/rocm/bin/hipcc"; }
+
+// Starts the compilation of one shape (returns the child's pid, 0 if the object is in the cache already, -1 on failure).
+inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint64_t hsh, std::string &err)
+{
+    const std::string base = cache + "/" + name_of(s, hsh), so = base + ".so";
+    if (exists(so)) return 0;
+    if (!exists(source_dir() + "/hmpc_kernel.hip")) { err = "kernel sources not found in " + source_dir(); return -1; }
+    if (access(compiler().c_str(), X_OK) != 0) { err = "no compiler at " + compiler(); return -1; }
+    char tag[32];
+    snprintf(tag, sizeof tag, ".%d", (int)getpid());
+    const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp.so";
+    {
+        std::ofstream out(src);
+        out << "// generated by hmpc_jit.h: the register kernel of one problem shape\n#define HMPC_KERNEL_ONLY\n#define HMPC_JIT_KC " << s.kc
+            << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", " << s.nu << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", "
+            << s.kt << ", " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<" << s.nx << ", " << s.nu
+            << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", " << s.kt << ", " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", " << s.nu << ", "
+            << s.nub << ", " << s.kf << ", " << s.kb << ", " << s.kt << ", " << s.nw << ", true>;\n}\n";
+        if (!out) { err = "cannot write " + src; return -1; }
+    }
+    // the compiler runs as a CHILD process (posix_spawn, as Python's subprocess does): nothing of this process is replaced
+    const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed -I '" + include_dir() + "' -I '" +
+                            source_dir() + "' -shared -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
+    pid_t pid = -1;
+    const char *argv[] = {"sh", "-c", cmd.c_str(), nullptr};
+    if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char *const *)argv, environ) != 0) { err = "cannot start the compiler"; return -1; }
+    return pid;
+}
+
+inline bool finish_build(pid_t pid, const hmpc_jit_shape &s, const std::string &cache, uint64_t hsh, std::string &err)
+{
+    const std::string base = cache + "/" + name_of(s, hsh);
+    if (pid > 0) {
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0) { }
+        char tag[32];
+        snprintf(tag, sizeof tag, ".%d", (int)getpid());
+        if (!(WIFEXITED(status) && WEXITSTATUS(status) == 0)) {
+            std::ifstream log(base + tag + ".log");
+            std::stringstream ss;
+            ss << log.rdbuf();
+            std::string t = ss.str();
+            err = "compilation of " + name_of(s, hsh) + " failed: " + (t.size() > 600 ? t.substr(t.size() - 600) : t);
+            return false;
+        }
+        (void)unlink((base + tag + ".hip").c_str());
+        (void)unlink((base + tag + ".log").c_str());
+    }
+    return exists(base + ".so");
+}
+
+} // namespace hmpc_jit
+
+// Builds (or finds in the cache) the kernels of `count` shapes, all compilations in flight together.  paths: the shared
+// objects, empty where a shape could not be built.  No GPU is touched.
+inline bool hmpc_jit_build_all(const hmpc_jit_shape *shapes, int count, std::vector<std::string> &paths, std::string &err)
+{
+    paths.assign(count, std::string());
+    const char *e = getenv("HMPC_JIT");
+    if (e && atoi(e) == 0) { err = "HMPC_JIT=0"; return false; }
+    const std::string cache = hmpc_jit::cache_dir();
+    if (cache.empty()) { err = "no writable cache directory"; return false; }
+    const uint64_t hsh = hmpc_jit::source_hash();
+    std::vector<pid_t> pid(count, -1);
+    for (int i = 0; i < count; i++) pid[i] = hmpc_jit::start_build(shapes[i], cache, hsh, err);
+    bool all = true;
+    for (int i = 0; i < count; i++) {
+        if (pid[i] >= 0 && hmpc_jit::finish_build(pid[i], shapes[i], cache, hsh, err)) paths[i] = cache + "/" + hmpc_jit::name_of(shapes[i], hsh) + ".so";
+        else all = false;
+    }
+    return all;
+}
+
+#endif // HMPC_JIT_H

@@ -54,7 +54,7 @@
 // shape its two more live values move the register allocation (scratch 124 -> 140 B per lane), and no optimal node of
 // the cart-pole systems has ever reached it (every one polishes: 0 of 165 824 + 40 424 + 21 000 nodes of the parity sweeps).
 // -DHMPC_ESC_ALL compiles it into every kernel (A/B builds).
-#ifdef HMPC_ESC_ALL
+#if defined(HMPC_ESC_ALL) || defined(HMPC_JIT_KC) // (kernels compiled at hmpc_create serve arbitrary systems: always with it)
 #define HMPC_ESC_ENABLED(D) true
 #else
 #define HMPC_ESC_ENABLED(D) (D::kNX <= 0)
@@ -65,7 +65,11 @@
 // (132 B of scratch instead of 124).  lam_0 from its row stays out of the cart-pole kernels: their D stays orders of
 // magnitude smaller (every optimal node ends at the polish, mu ~ 1e-9), the row's error with it.
 #ifndef HMPC_LAM0_ROW
+#ifdef HMPC_JIT_KC
+#define HMPC_LAM0_ROW 1
+#else
 #define HMPC_LAM0_ROW 0
+#endif
 #endif
 #ifndef HMPC_STABLE_DEN
 #define HMPC_STABLE_DEN 1
@@ -278,7 +282,12 @@ struct Dims {
     static constexpr bool kBig = NX_ < 0;
     // entries per padded column of the stage rows (compile-time shapes): the cart-pole systems have at
     // most 14 (nu = 7) and 8 (nu = 4); a problem of the same shape with fuller columns takes the generic kernel
+#ifdef HMPC_JIT_KC // (a kernel compiled at hmpc_create for a shape without a built-in instantiation, hmpc_jit.h: the host
+                   // passes the longest column of the problem's stage rows, rounded up to an even number)
+    static constexpr int kKC = NX_ > 0 ? HMPC_JIT_KC : 0;
+#else
     static constexpr int kKC = NX_ > 0 ? (NU_ == 7 ? 14 : 8) : 0;
+#endif
     static DEV int nx(const DevProb &p) { return NX_ > 0 ? NX_ : p.nx; }
     static DEV int nu(const DevProb &p) { return NU_ > 0 ? NU_ : p.nu; }
     static DEV int nub(const DevProb &p) { return NU_ > 0 ? NUB_ : p.nub; }
@@ -644,12 +653,15 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
     static constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
     static constexpr int kSlots = KF + KB + KT, kSlotsFB = KF + KB;
     static constexpr int SB = D::kNT / (2 * NUB); // stages per slot of bound rows
-    static_assert(D::kNT % (2 * NUB) == 0, "bound rows must tile the workgroup");
+    // (2 NUB need not divide the workgroup -- three binaries: 10 stages of 6 rows on 64 lanes --: the lanes past the last
+    // whole stage hold no bound row; for the shapes whose bound rows tile the workgroup the test folds away)
+    static constexpr bool kAllB = D::kNT % (2 * NUB) == 0;
+    static_assert(SB >= 1, "one stage's bound rows must fit the workgroup");
     struct Ref { int e, v, row; };
     double cx[NX], cu[2], hF, sgB, hB;
     int uo[2];
     int SP, sE, sV, tF0, eF0, vF0, tB0, eB0, vB0, bB;
-    bool okF;
+    bool okF, okB;
     unsigned act; // bit k: the row of slot k takes part in the current solve
     DEV void init(const DevProb &p, int lane)
     {
@@ -676,6 +688,7 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
         const int cB = lane % (2 * NUB);
         bB = cB % NUB;
         tB0 = lane / (2 * NUB);
+        okB = kAllB || lane < SB * 2 * NUB;
         eB0 = tB0 * p.mreg + nc + cB;
         vB0 = tB0 * NZ + NX + NUC + bB;
         sgB = p.Creg[(size_t)(nc + cB) * NZ + NX + NUC + bB];
@@ -700,7 +713,7 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
             rw.e = e0 + kb * SB * p.mreg;
             rw.v = v0 + kb * SB * NZ;
             rw.row = 0;
-            return tB0 + kb * SB < p.T;
+            return (kAllB || okB) && tB0 + kb * SB < p.T;
         } else {
             int row = (k - KF - KB) * D::kNT + lane;
             ROW_OPAQUE(row);
@@ -721,7 +734,7 @@ template <class D, int KF, int KB, int KT> struct RowMapS {
             if (k < KF) on = true;
             else if (k < KF + KB) {
                 const int t = tB0 + (k - KF) * SB;
-                on = t < p.T && S.fix[(t < p.T ? t : 0) * NUB + bB] < 0;
+                on = (kAllB || okB) && t < p.T && S.fix[(t < p.T ? t : 0) * NUB + bB] < 0;
             } else on = term_on != 0;
             act |= (on ? 1u : 0u) << k;
         }
@@ -1535,6 +1548,30 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 S.Mm[gi * NZ + gj] = g0 + g1;
                 S.Mm[gj * NZ + gi] = g0 + g1;
             }
+#ifdef HMPC_JIT_KC
+            // kernels compiled for an arbitrary shape: entries 64 .. 127 of C' D C with a term list (nz = 15 with dense state
+            // rows has ~90) take a second trip; their per-lane constants are fetched per stage instead of being held.  The
+            // shipped cart-pole shapes have at most 64 such entries (checked on the host) and none of this code.
+            if (ng > WAVE) {
+                const bool has2 = WAVE + lane < ng;
+                const int ge2 = has2 ? WAVE + lane : 0;
+                const int gi2 = S.ei[ge2], gj2 = S.ej[ge2];
+                const int gq0 = S.L0.gptr[ge2], glen2 = has2 ? S.L0.gptr[ge2 + 1] - gq0 : 0;
+                const ldsd *Dt = S.e + t * p.mreg;
+                double h0 = S.P[gi2 * NZ + gj2], h1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < KG; q++) {
+                    const int qq = gq0 + (q < glen2 ? q : 0);
+                    const double term = q < glen2 ? S.L0.gval[qq] * Dt[S.L0.grow[qq]] : 0.0;
+                    if (q & 1) h1 += term;
+                    else h0 += term;
+                }
+                if (has2) {
+                    S.Mm[gi2 * NZ + gj2] = h0 + h1;
+                    S.Mm[gj2 * NZ + gi2] = h0 + h1;
+                }
+            }
+#endif
             // (2) column `lane` of W = [A B]' P_{t+1} [A B]
             double y[NX];
 #pragma unroll
@@ -3736,7 +3773,7 @@ static int hmpc_waves_for(int B, int resident_nodes)
 static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &kt)
 {
     const int nt = nw * WAVE;
-    if (!p.static_rows || p.nc < 1 || p.nc > nt || p.nub < 1 || nt % (2 * p.nub) != 0) return false;
+    if (!p.static_rows || p.nc < 1 || p.nc > nt || p.nub < 1 || 2 * p.nub > nt) return false;
     const int sp = nt / p.nc, sb = nt / (2 * p.nub);
     kf = (p.T + sp - 1) / sp;
     kb = (p.T + sb - 1) / sb;
@@ -3746,7 +3783,9 @@ static bool hmpc_static_slots(const DevProb &p, int nw, int &kf, int &kb, int &k
 #define HMPC_TRY(NX, NU, NUB, F, Bn, Tn, NWv) \
     if (kf <= F && kb <= Bn && kt <= Tn && p.kcol <= Dims<NX, NU, NUB, NWv>::kKC)       \
         return {hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv>, hmpc_qp_kernel<NX, NU, NUB, F, Bn, Tn, NWv, true>, NWv, Dims<NX, NU, NUB, NWv>::kKC, 0};
-static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
+// jit (optional): kernels compiled for this problem's shape at hmpc_create (hmpc_jit.h), by log2 of the waves per node;
+// fn null where there is none.
+static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw, const hmpc_kernel_choice *jit = nullptr)
 {
 #ifdef HMPC_DEV_BIG_ONLY
     // development build (`make dev`): only the streaming form of the generic kernel is instantiated (compiles in a
@@ -3756,7 +3795,7 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
 #else
     const bool generic = getenv("HMPC_FORCE_GENERIC") != nullptr || getenv("HMPC_FORCE_BIG") != nullptr;
     int kf = 0, kb = 0, kt = 0;
-    if (!generic && p.nx == 4 && p.nu == 7 && p.nub == 4) {
+    if (!generic && p.ngram <= WAVE && p.nx == 4 && p.nu == 7 && p.nub == 4) {
         // smallest instantiation that holds the rows; fewer waves than asked for never fit more rows
         for (int w = nw; w <= 4; w *= 2) {
             if (!hmpc_static_slots(p, w, kf, kb, kt)) continue;
@@ -3765,11 +3804,17 @@ static hmpc_kernel_choice hmpc_pick_kernel(const DevProb &p, int nw)
             if (w == 4) { HMPC_TRY(4, 7, 4, 3, 1, 1, 4) HMPC_TRY(4, 7, 4, 5, 2, 1, 4) }
         }
     }
-    if (!generic && p.nx == 4 && p.nu == 4 && p.nub == 2) {
+    if (!generic && p.ngram <= WAVE && p.nx == 4 && p.nu == 4 && p.nub == 2) {
         for (int w = nw < 2 ? 2 : nw; w <= 4; w *= 2) {
             if (!hmpc_static_slots(p, w, kf, kb, kt)) continue;
             if (w == 2) { HMPC_TRY(4, 4, 2, 7, 2, 1, 2) }
             if (w == 4) { HMPC_TRY(4, 4, 2, 4, 1, 1, 4) }
+        }
+    }
+    if (!generic && jit) {
+        for (int w = nw; w <= 4; w *= 2) {
+            const hmpc_kernel_choice &j = jit[w == 1 ? 0 : w == 2 ? 1 : 2];
+            if (j.fn) return j;
         }
     }
     // generic kernel; its streaming form when lists and factor do not fit one CU's LDS

@@ -128,12 +128,55 @@ def load_library():
     return _lib
 
 
-EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info',
+EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_build',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_stop', 'hmpc_fleet_rows', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
                     'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_allreduce_incumbent_device', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
+
+
+def jit_shapes(problem):
+    """The register-kernel shapes ``hmpc_create`` compiles for ``problem`` (csrc/hmpc_jit.h): a list of
+    (nx, nu, nub, kf, kb, kt, nw, kc) for 1 / 2 / 4 waves per node, empty where the static row map does not hold the
+    problem (nx + nu > 16, an [F G] row with more than two input coefficients, no binary, a built-in shape).  Mirrors the
+    host code of ``hmpc_create`` / ``hmpc_static_slots``; used to warm the cache ahead of time (``jit_prebuild``)."""
+    nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
+    F, G = np.atleast_2d(problem['F']), np.atleast_2d(problem['G'])
+    nc, nT = F.shape[0], np.atleast_2d(problem['F_Tm1']).shape[0] - F.shape[0]
+    if (nx, nu, nub) in ((4, 7, 4), (4, 4, 2)) or nx + nu > 16 or nub < 1 or nc + 2 * nub > 255:
+        return []
+    if np.any(np.count_nonzero(G, axis=1) > 2):
+        return []
+    col = np.concatenate((np.count_nonzero(F, axis=0), np.count_nonzero(G, axis=0)))
+    col[nx + nu - nub:] += 2                                    # the two bound rows of a binary
+    kc = max(2, (int(col.max()) + 1) // 2 * 2)
+    if kc > 16:
+        return []
+    out = []
+    for nw in (1, 2, 4):
+        nt = 64 * nw
+        if nc > nt or 2 * nub > nt:
+            continue
+        kf, kb, kt = -(-T // (nt // nc)), -(-T // (nt // (2 * nub))), max(1, -(-nT // nt))
+        if kf + kb + kt <= 16:
+            out.append((nx, nu, nub, kf, kb, kt, nw, kc))
+    return out
+
+
+def jit_prebuild(problem):
+    """Compiles (or finds in the cache) the register kernels ``hmpc_create`` would compile for ``problem`` -- without a GPU
+    (``hmpc_jit_build``).  Returns the paths of the shared objects."""
+    lib = load_library()
+    lib.hmpc_jit_build.restype = ctypes.c_int
+    lib.hmpc_jit_build.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_char_p, ctypes.c_int32]
+    paths = []
+    for shape in jit_shapes(problem):
+        buf = ctypes.create_string_buffer(1024)
+        if lib.hmpc_jit_build(*shape, buf, 1024) != 0:
+            raise RuntimeError('hmpc_jit_build%r failed: %s' % (shape, lib.hmpc_last_error().decode()))
+        paths.append(buf.value.decode())
+    return paths
 
 
 def lp_solve_batch(A, c, b, relax=None, tol=1e-9, max_iter=100, device=-1):
@@ -291,6 +334,15 @@ class HipBatchedQP(object):
             w = ctypes.byref(_Warm(wp.data_ptr(), wd.data_ptr(), wi.data_ptr(), wp.shape[0]))
         self._check(self.lib.hmpc_solve_batch_device(self.handle, x0.data_ptr(), stride, fix.data_ptr(), B, w,
                                                      ctypes.byref(res), ctypes.c_void_p(stream)))
+
+    def kernel_info(self):
+        """Kind of kernel that serves this problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming form,
+        2 built-in register kernel, 3 register kernel compiled for this shape at creation (``hmpc_kernel_info``)."""
+        k = (ctypes.c_int32 * 3)()
+        self.lib.hmpc_kernel_info.restype = ctypes.c_int
+        self.lib.hmpc_kernel_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+        self._check(self.lib.hmpc_kernel_info(self.handle, k))
+        return tuple(int(v) for v in k)
 
     def launch_info(self):
         grid, lds = ctypes.c_int32(), ctypes.c_int32()
