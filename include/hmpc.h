@@ -49,7 +49,7 @@ extern "C" {
 
 #define HMPC_ITERS_POLISHED 0x10000 /* flag in hmpc_result.iters */
 #define HMPC_ITERS_WEAK 0x20000     /* flag in hmpc_result.iters: HMPC_INFEASIBLE, but the ray is no proof to tolerance */
-#define HMPC_ITERS_TERMINAL 0x80000 /* flag in hmpc_result.iters (launches with hmpc_warm only): the terminal-set rows were needed */
+#define HMPC_ITERS_TERMINAL 0x80000 /* flag in hmpc_result.iters (launches with hmpc_warm, and large cold batches in the two-launch form): the terminal-set rows were needed */
 #define HMPC_ITERS_HANDED 0x40000   /* flag in hmpc_result.iters: the active set handed down by the parent (hmpc_warm) verified */
 
 /* return codes */

@@ -405,6 +405,39 @@ def test_register_kernel_compiled_for_an_arbitrary_shape():
         np.testing.assert_allclose(g['obj'][fin], a['obj'][fin], rtol=1e-8, atol=1e-11)
 
 
+def test_two_launch_form_of_the_lazy_terminal_set(monkeypatch):
+    # Opt-in (HMPC_SPLIT=1): large cold batches leave the nodes that need the terminal-set rows to a second launch (four
+    # waves per node, each from its own first record: hmpc_capi.hip, DevWarm).  Same statuses and the same vertices as the
+    # one-launch form and as the oracle; the nodes of real trees from closed-loop states: ~6 % of them take that path.
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import real_tree_frontier
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    x0, fix, _ = real_tree_frontier(hip, 2048, 0, load_fixture('cart_pole_with_walls')['x_max'], spread=0.05)
+    monkeypatch.setenv('HMPC_SPLIT', '1')            # (opt-in: measured slower than the one-launch form, hmpc_capi.hip)
+    a = hip.qp.solve_batch(x0, fix)
+    monkeypatch.delenv('HMPC_SPLIT')
+    b = hip.qp.solve_batch(x0, fix)
+    assert hip.qp.launch_info()[0] >= 1024                                # (one wave per node: the form that splits)
+    assert 20 <= a['second'].sum() <= 400 and b['second'].sum() == 0   # (the one-launch cold kernel does not raise the flag)
+    assert np.array_equal(a['status'], b['status']) and np.all(a['status'] <= 1)
+    fin = a['status'] == 0
+    assert np.all(a['polished'][fin] > 0) and np.all(b['polished'][fin] > 0)
+    np.testing.assert_allclose(a['obj'][fin], b['obj'][fin], rtol=1e-9, atol=1e-12)
+    xs = 21 * 4
+    dev = np.max(np.abs(a['primal'][fin][:, :xs] - b['primal'][fin][:, :xs]), axis=1) / np.maximum(1e-2, np.max(np.abs(b['primal'][fin][:, :xs]), axis=1))
+    assert dev.max() < 1e-7, dev.max()
+    differ = int((a['iters'] != b['iters']).sum())                          # (the second solves: fewer iterations from the first record)
+    assert 20 <= differ <= 400 and a['iters'][a['iters'] != b['iters']].mean() < b['iters'][a['iters'] != b['iters']].mean()
+    inf = a['status'] == 1
+    np.testing.assert_allclose(a['dual'][inf], b['dual'][inf], rtol=0, atol=1e-6)
+    orc = make_controller('cart_pole_with_walls', backend='oracle', threads=8)
+    sub = np.flatnonzero(a['iters'] != b['iters'])[:64]
+    sub = np.concatenate((sub, np.arange(64)))
+    _compare(hip, {k: v[sub] for k, v in a.items() if isinstance(v, np.ndarray) and v.shape[:1] == (len(fix),)},
+             orc.qp.solve_batch(x0[sub], fix[sub]), 20, fix[sub], x0=x0[sub])
+
+
 def test_streaming_kernel_baseline_config4():
     # BASELINE.json configs[4] (random MLD nx=20, nu=6+8, N=30; rows as in SURVEY 8(d) C4): lists and
     # Riccati factor do not fit one CU's LDS, the generic kernel's streaming form keeps them in global memory

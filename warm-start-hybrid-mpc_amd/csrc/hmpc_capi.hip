@@ -47,6 +47,8 @@ struct hmpc_handle {
     double *rows_ws = nullptr;
     int32_t *order = nullptr; // processing order of large frontiers (hmpc_order_kernel)
     int order_cap = 0;
+    int32_t *pend = nullptr;  // two-launch form of the lazy terminal set: [0] how many nodes wait for their second solve, [1 ..] which
+    int pend_cap = 0;
     void *d_shift = nullptr; // staging of the host-pointer shift
     size_t shift_staged = 0;
     double *trace = nullptr;
@@ -492,6 +494,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     for (void *d : h->allocs) (void)hipFree(d);
     if (h->rows_ws) (void)hipFree(h->rows_ws);
     if (h->order) (void)hipFree(h->order);
+    if (h->pend) (void)hipFree(h->pend);
     if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->trace) (void)hipFree(h->trace);
     if (h->d_x0) (void)hipFree(h->d_x0);
@@ -660,10 +663,10 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
-    DevWarm w{nullptr, nullptr, nullptr};
+    DevWarm w{nullptr, nullptr, nullptr, nullptr, 0};
     if (d_warm && d_warm->index) {
         if (!d_warm->primal || !d_warm->dual) return fail(HMPC_EINVAL, "hmpc_warm: index without record rows");
-        w = DevWarm{d_warm->primal, d_warm->dual, d_warm->index};
+        w = DevWarm{d_warm->primal, d_warm->dual, d_warm->index, nullptr, 0};
     }
     int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
     // the streaming form holds one node per CU whatever the number of waves: always spread it over all four SIMDs
@@ -690,9 +693,43 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
         hipLaunchKernelGGL(hmpc_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_fix, B, h->dp.T * h->dp.nub, order, w,
                            (h->dp.T + 1) * h->dp.nx + (h->dp.T - 1) * h->dp.nc + h->dp.nc, h->dp.nT, h->dp.n_dual);
     }
+    // TWO-LAUNCH FORM of the lazy terminal set (DevWarm; round 4; OPT-IN: HMPC_SPLIT=1): a large cold batch of a register
+    // kernel with one wave per node.  A node that needs the terminal-set rows takes 24+ iterations where the others take
+    // 7 - 12, and at one wave per node it is the tail of the launch wherever it starts (6 % of the nodes of real closed-loop
+    // trees: 12.4 ms per 4096 nodes against 9.0 without them).  The first launch leaves those nodes to a second one: four
+    // waves per node, each from its own first record -- the active set of the masked solve plus the terminal rows it
+    // violates: 232 of 238 such nodes verify that way in a few rounds (11.5 instead of 13.6 iterations per optimal node).
+    // Same statuses, same vertices (1e-9).  MEASURED SLOWER, which is why it is not the default: 13.05 ms against 12.44 --
+    // the six nodes whose own set does not verify (infeasible with the terminal set: they owe a certificate) run a full
+    // second solve, 24 iterations = 3 ms even at four waves, ALONE on the device: the tail has moved into a launch of its
+    // own.  What would pay is knowing those nodes before their first solve (profiles/r04_split.txt).
+    const hmpc_cfg &c4 = h->cfg[2];
+    const bool split = !w.index && nw == 1 && k.kc > 0 && c4.k.kc > 0 && h->dp.nT > 0 && h->dp.lazy && h->dp.polish && o.primal && o.dual && o.iters &&
+                       o.status && getenv("HMPC_SPLIT") && !h->trace;
+    if (split) {
+        if (B + 1 > h->pend_cap) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            if (h->pend) (void)hipFree(h->pend);
+            h->pend = nullptr;
+            h->pend_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->pend, (size_t)(B + B / 2 + 1) * sizeof(int32_t)));
+            h->pend_cap = B + B / 2 + 1;
+        }
+        HIPCHK(hipMemsetAsync(h->pend, 0, sizeof(int32_t), (hipStream_t)stream));
+        w.pend = h->pend;
+    }
     hipLaunchKernelGGL(w.index ? k.fn_warm : k.fn, dim3(grid), dim3(64 * k.waves), cf.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride,
                        d_fix, B, o, h->rows_ws, h->trace, (const int32_t *)order, w);
     HIPCHK(hipGetLastError());
+    if (split) {
+        // (how many nodes wait is known on the device only: enough workgroups for all of them, those without a node leave at once)
+        const int grid2 = B < c4.max_grid ? B : c4.max_grid;
+        HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), (hipStream_t)stream));
+        DevWarm w2{o.primal, o.dual, nullptr, h->pend, 1};
+        hipLaunchKernelGGL(c4.k.fn_warm, dim3(grid2), dim3(64 * c4.k.waves), c4.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride, d_fix, B, o, h->rows_ws,
+                           h->trace, (const int32_t *)nullptr, w2);
+        HIPCHK(hipGetLastError());
+    }
     return HMPC_OK;
 }
 

@@ -74,6 +74,14 @@ struct DevOut {
 struct DevWarm {
     const double *primal, *dual;
     const int32_t *index;
+    // TWO-LAUNCH FORM of the lazy terminal set (large cold batches, hmpc_solve_batch_device): the first launch solves every
+    // node with the terminal-set rows masked and, instead of solving a node that needs them a second time in place --
+    // 24+ iterations at one wave per node among short nodes: the tail of the launch --, appends it to `pend` (pend[0]: how
+    // many, pend[1 ..]: which); the second launch (`second` set; four waves per node) takes those nodes only, each from its
+    // own first record (primal / dual are then the output arrays): the active set of the masked solve plus the terminal
+    // rows it violates is tried before anything else.
+    int32_t *pend;
+    int32_t second;
 };
 
 // LDS bytes per workgroup (must mirror the carve in hmpc_qp_kernel).  kc: entries per padded column of

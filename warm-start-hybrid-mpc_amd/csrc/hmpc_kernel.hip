@@ -80,6 +80,9 @@
 #define HMPC_POLISH_ATTEMPTS 3 // per solve: a node whose active set resists is left to the interior-point iterate
 #define HMPC_RETRY (-1) // internal: a hand-down attempt with the terminal-set rows did not verify, run the regular sequence
 #define HMPC_POLISH_ROUNDS_WARM 3 // active sets tried when the set is handed down by the parent node
+#ifndef HMPC_POLISH_ROUNDS_OWN
+#define HMPC_POLISH_ROUNDS_OWN 8 // ... and when it is the node's own (second launch of the two-launch form of the lazy terminal set)
+#endif
 #define HMPC_POLISH_WARM_BMOVE 0.5 // a hand-down is not tried where a fixed binary lies further than this from the parent's value
 #define HMPC_POLISH_WARM_VMAX 1e-2 // a handed-down set whose point misses an inactive row by more is dropped at once
 #ifndef HMPC_KERNEL_ATTR
@@ -2534,7 +2537,7 @@ template <class D> DEV double dPd(const DevProb &p, const Lds &S, int lane, cons
 template <class D, int RS, class RM, bool WARM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
                   bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual,
-                  bool attempt_only)
+                  bool attempt_only, bool own = false)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
     const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -2936,7 +2939,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         if (mode != 0) {
             // ---------------- polish: multiplier step, verification, next pass ----------------
             int outcome = 0; // 0 give up, 1 verified, 2 next pass
-            const int max_rounds = (WARM && warm_try) ? HMPC_POLISH_ROUNDS_WARM : attempts > HMPC_POLISH_ATTEMPTS ? HMPC_POLISH_ROUNDS_LAST : HMPC_POLISH_ROUNDS;
+            // (own: the second launch of the two-launch form -- the set is the node's OWN masked solve's, and what is missing
+            // are the terminal rows that solve violates: they enter over the rounds, whatever their violation to begin with)
+            const int max_rounds = (WARM && warm_try) ? (own ? HMPC_POLISH_ROUNDS_OWN : HMPC_POLISH_ROUNDS_WARM)
+                                                      : attempts > HMPC_POLISH_ATTEMPTS ? HMPC_POLISH_ROUNDS_LAST : HMPC_POLISH_ROUNDS;
             if (mode != 3) {
                 double pinf = 0, pmove = 0;
                 ROWS_BEGIN(k, rw)
@@ -2988,7 +2994,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // multipliers (what is left to settle are the components that matter, of the size of the
                             // second level's rounding; the slow ones are in place)
                             act = (level == 1 && round + 1 < max_rounds) ? 2 : 0;
-                        } else if (WARM && warm_try && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
+                        } else if (WARM && warm_try && !own && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
                             // the handed-down set is not near this node's optimum (the node is infeasible, or fixing the
                             // binary moved the solution): dropped after this one factorisation
                         } else if (round + 1 < max_rounds) {
@@ -3543,11 +3549,14 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
     // first gridDim.x nodes go to the workgroups by index, every further node to the first workgroup that is free
     // (one atomic per node on a counter the host zeroes before the launch).  A record does not depend on the
     // workgroup that computes it.
-    for (int slot = blockIdx.x; slot < B;) {
+    int Bn = B; // nodes of this launch (a second pass of the two-launch form reads their number from the device)
+    if constexpr (WARM) { if (warm.second) Bn = warm.pend[0]; }
+    for (int slot = blockIdx.x; slot < Bn;) {
         // `order` (optional): the nodes sorted by the number of fixed binaries, shallow first -- shallow nodes take more
         // iterations (correlation -0.5 .. -0.75 on random frontiers), and with ~4 nodes per workgroup handing out the
         // long ones first shortens the tail of a launch
-        const int qp = order ? order[slot] : slot;
+        int qp = order ? order[slot] : slot;
+        if constexpr (WARM) { if (warm.second) qp = warm.pend[1 + slot]; }
         __syncthreads();
         for (int o = lane; o < T * nub; o += D::kNT) S.fix[o] = fixg[(size_t)qp * T * nub + o];
         for (int i = lane; i < nx; i += D::kNT) S.x0[i] = x0g[(size_t)qp * x0_stride + i];
@@ -3578,7 +3587,7 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
         double *tr = (trace && qp == 0) ? trace : nullptr;
         const double *wprim = nullptr, *wdual = nullptr; // the parent's record, if one is handed down
         if constexpr (WARM) {
-            const int wrow = warm.index ? warm.index[qp] : -1;
+            const int wrow = warm.second ? qp : warm.index ? warm.index[qp] : -1;
             wprim = wrow >= 0 ? warm.primal + (size_t)wrow * p.n_primal : nullptr;
             wdual = wrow >= 0 ? warm.dual + (size_t)wrow * p.n_dual : nullptr;
         }
@@ -3596,6 +3605,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
                     bool done = status == HMPC_INFEASIBLE;
                     if (status == HMPC_OPTIMAL) done = terminal_violation<D>(p, S, lane, tau) < 0.0;
                     if (done) break;
+                    if (warm.pend) { // two-launch form: the second solve is the second launch's (DevWarm)
+                        if (lane == 0) warm.pend[1 + atomicAdd(warm.pend, 1)] = qp;
+                        break;
+                    }
                 }
             }
             // (HMPC_ITERS_TERMINAL is raised by the hand-down instantiations only: in this one the flag -- one more value
@@ -3607,7 +3620,10 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
             // sequence -- masked first, so that an infeasible node's ray carries no terminal multipliers -- runs as without
             // it.  Same steps as oracle/hsde_qp.c.
             int stage = first;
-            if (wdual != nullptr && p.polish && first == 0) {
+            if (warm.second) { // second launch of the two-launch form: terminal rows on, from the node's own first record
+                stage = 2;
+                it1 = out.iters ? (out.iters[qp] & 0xFFFF) : 0;
+            } else if (wdual != nullptr && p.polish && first == 0) {
                 double m = 0.0;
                 for (int k = lane; k < p.nT; k += D::kNT) m = fmax(m, wdual[(T + 1) * nx + (T - 1) * p.nc + p.nc + k]);
                 if (block_max<D>(m, S.red, lane) > 0.0) stage = 2;
@@ -3616,10 +3632,11 @@ hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, c
                 const int term_on = stage == 0 ? 0 : 1;
                 int its = 0;
                 S.term_on = term_on;
-                status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, stage == 2);
+                status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, stage == 2,
+                                                    stage == 2 && warm.second != 0);
                 if (stage == 2) {
-                    if (status == HMPC_RETRY) { stage = 0; continue; }
-                    it1 = its;
+                    if (status == HMPC_RETRY) { stage = warm.second ? 1 : 0; continue; }
+                    if (warm.second) it2 = its; else it1 = its;
                     second = true;
                     break;
                 }

@@ -307,6 +307,7 @@ class HipBatchedQP(object):
         out['handed'] = (out['iters'] >> 18) & 1        # HMPC_ITERS_HANDED: the active set handed down by the parent verified
         out['polished'] = (out['iters'] >> 16) & 1      # HMPC_ITERS_POLISHED
         out['weak'] = (out['iters'] >> 17) & 1          # HMPC_ITERS_WEAK: infeasible, the ray is no proof to tolerance
+        out['second'] = (out['iters'] >> 19) & 1        # HMPC_ITERS_TERMINAL: the terminal-set rows were needed (hand-down launches and the two-launch form)
         out['iters'] = out['iters'] & 0xFFFF
         return out
 
