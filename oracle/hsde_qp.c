@@ -800,7 +800,12 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
              * no feasible point -- is taken (the node is pruned, as a simplex code with a 1e-6 feasibility tolerance
              * would), but the ray is flagged WEAK: it prunes this node and nothing else -- the warm-start shift never
              * carries it to the next step (the leaf is reopened). */
-            if (eta > 0 && tau <= 1e-8 * kap && cert <= 0.5 * eta) {
+            /* (d) (round 4) tau has collapsed four more decades and still no ray verifies: a node on the very boundary between
+             * feasible and infeasible -- f'y + h'z and E'y + C'z both go to zero, eta changes sign from one iteration to the
+             * next (tests/golden/hard_node_sd003.npz, from the replay of the published sd = .003 runs with cold searches
+             * only: the kernel ran it to 100 iterations, this code left at 37 through (b) by the luck of its rounding).
+             * Same conclusion and flag as (c). */
+            if ((eta > 0 && tau <= 1e-8 * kap && cert <= 0.5 * eta) || tau <= 1e-12 * kap) {
                 status = ST_INFEASIBLE; weak = 1; break;
             }
         }

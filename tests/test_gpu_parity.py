@@ -438,6 +438,25 @@ def test_two_launch_form_of_the_lazy_terminal_set(monkeypatch):
              orc.qp.solve_batch(x0[sub], fix[sub]), 20, fix[sub], x0=x0[sub])
 
 
+@pytest.mark.parametrize('waves', ['1', '2', '4'])
+def test_a_node_on_the_boundary_between_feasible_and_infeasible_is_decided(monkeypatch, waves):
+    # tests/golden/hard_node_sd003.npz: met when the published sd = .003 runs are replayed with cold searches only (no
+    # hand-down: the reference's setting).  tau collapses while NO ray verifies -- f'y + h'z and E'y + C'z both go to zero,
+    # eta changes sign from one iteration to the next: the node is infeasible by less than the accuracy of the arithmetic.
+    # Until round 4 the kernel ran it to 100 iterations, twice, and could end MAXITER (the study stopped on it); the oracle
+    # leaves at iteration 37 with a ray that happens to verify.  Now: infeasible on both sides, the kernel's ray flagged
+    # WEAK (pruned at this step, never carried to the next), decided within ~40 iterations.
+    d = load_fixture('hard_node_sd003')
+    hip = make_controller('cart_pole_with_walls', backend='hip')
+    orc = make_controller('cart_pole_with_walls', backend='oracle')
+    monkeypatch.setenv('HMPC_WAVES', waves)
+    a = hip.qp.solve_batch(d['x0'][0], d['fix'])
+    monkeypatch.delenv('HMPC_WAVES')
+    b = orc.qp.solve_batch(d['x0'][0], d['fix'])
+    assert a['status'][0] == 1 and b['status'][0] == 1
+    assert a['iters'][0] <= 60 and (a['weak'][0] == 1 or b['weak'][0] == 0)
+
+
 def test_streaming_kernel_baseline_config4():
     # BASELINE.json configs[4] (random MLD nx=20, nu=6+8, N=30; rows as in SURVEY 8(d) C4): lists and
     # Riccati factor do not fit one CU's LDS, the generic kernel's streaming form keeps them in global memory

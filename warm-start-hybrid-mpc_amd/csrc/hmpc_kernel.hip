@@ -2839,7 +2839,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         // node is pruned, as by a simplex code with a 1e-6 feasibility tolerance -- but the ray is flagged WEAK
         // (HMPC_ITERS_WEAK): it prunes this node only, the warm-start shift never carries it to the next step.
         // Same rule as oracle/hsde_qp.c.
-        if (!polish && eta > 0 && tau <= 1e-8 * kap && certinf <= 0.5 * eta) {
+        if (!polish && ((eta > 0 && tau <= 1e-8 * kap && certinf <= 0.5 * eta) || tau <= 1e-12 * kap)) {
+            // (second clause, round 4: tau has collapsed four more decades and still no ray verifies -- a node on the very
+            // boundary between feasible and infeasible: f'y + h'z and E'y + C'z both go to zero, eta changes sign from one
+            // iteration to the next.  Met when the published sd = .003 runs are replayed with cold searches only
+            // (tests/golden/hard_node_sd003.npz): the kernel ran such a node to 100 iterations, twice, and could end MAXITER;
+            // the oracle left at iteration 37 through the clause above by the luck of its rounding.  Same conclusion, same
+            // flag: pruned at this step, never carried to the next.  Same rule as oracle/hsde_qp.c.)
             status = HMPC_INFEASIBLE;
             weak_out = true;
             break;
