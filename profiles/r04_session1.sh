@@ -2,6 +2,8 @@
 # Round 4, GPU session 1 (through gpurun from the repo root: bash profiles/r04_session1.sh): the -m gpu suite with the
 # tolerance escalation (configs[4] at 4096 nodes, one RTOL), A/B of the escalation compiled into the register kernels,
 # bench.py starting its own ranks (rehearsal on one GPU).
+# libhmpc_esc.so: the same tree built with -DHMPC_ESC_ALL (make OUT=../libhmpc_esc.so BUILD=build_esc CXXFLAGS="... -DHMPC_ESC_ALL"):
+# the escalation compiled into the cart-pole kernels as well.  Result: 8.602 / 8.603 ms against 8.639 / 8.639 (+0.4 %), same records.
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04
 mkdir -p $O

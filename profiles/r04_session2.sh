@@ -1,6 +1,9 @@
 #!/bin/bash
 # Round 4, GPU session 2: A/B of the accuracy changes in the cart-pole kernels (lam_0 from its row, stable denominator),
 # then the -m gpu suite on the default build, then the escalation diagnostic on configs[4].
+# libhmpc.so here: -DHMPC_LAM0_ROW=1 -DHMPC_STABLE_DEN=1 in the cart-pole kernels; libhmpc_b.so: -DHMPC_LAM0_ROW=0; libhmpc_c.so: both 0
+# (make OUT=.. BUILD=.. CXXFLAGS=..).  Result, ms per 4096 nodes, two runs each: 8.654 / 8.658, 8.585 / 8.559, 8.570 / 8.546; identical
+# iteration counts and records.  The final tree ships variant b (stable denominator only) for the cart-pole kernels.
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r04
 mkdir -p $O
