@@ -61,6 +61,7 @@ typedef struct {
     double *sreg, *slast;                /* row scales of the general rows  */
     double *P, *PT;                      /* 2*cs*(Q'Q (+) R'R), 2*cs*QT'QT   */
     double cs;                           /* cost scale                       */
+    int polish_l1;                       /* 1: curvature of the scaled cost of order one -- the polish starts and ends at its second penalty level (hmpc_device.h) */
     int *roff;                           /* first row of stage t            */
 } prob_t;
 
@@ -125,6 +126,12 @@ static prob_t *prob_create(int nx, int nu, int nub, int T, int nc, int ncL, int 
     p->cs = big > 0 ? 1.0 / big : 1.0;
     for (int i = 0; i < nz * nz; i++) p->P[i] *= p->cs;
     for (int i = 0; i < nx * nx; i++) p->PT[i] *= p->cs;
+    {   /* curvature of the scaled cost: smallest positive diagonal entry (as hmpc_create) */
+        double cmin = 1.0;
+        for (int i = 0; i < nz; i++) if (p->P[i * nz + i] > 0 && p->P[i * nz + i] < cmin) cmin = p->P[i * nz + i];
+        for (int i = 0; i < nx; i++) if (p->PT[i * nx + i] > 0 && p->PT[i * nx + i] < cmin) cmin = p->PT[i * nx + i];
+        p->polish_l1 = cmin >= 1e-2 ? 1 : 0;
+    }
     p->roff = (int *)malloc(sizeof(int) * (T + 1));
     for (int t = 0; t <= T; t++) p->roff[t] = t < T ? t * p->mreg : p->M;
     return p;
@@ -464,8 +471,8 @@ static double vmaxabs(const double *v, int n) { double m = 0; for (int i = 0; i 
 static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fix, double tau, double winf, double zinf, double last_alpha, const double *zwarm, int last)
 {
     int nz = p->nz, T = p->T;
-    double rho = POLISH_RHO;
-    int level = 0; /* 0: first penalty level; 1: second; 2: back at the first for the last digits */
+    double rho = p->polish_l1 ? POLISH_RHO2 : POLISH_RHO;
+    int level = p->polish_l1; /* 0: first penalty level; 1: second; 2: back at the first for the last digits */
     double *zk = k->dza, *cw = k->dsa, *cw0 = k->ec;
     for (int t = 0; t < T; t++) {
         const double *C = Ct(p, t); int m = mt(p, t), ro = p->roff[t];
@@ -566,7 +573,7 @@ static int polish(const prob_t *p, work_t *k, const double *x0, const int8_t *fi
          * infeasible, or fixing the binary moved the solution): drop it after this one factorisation */
         if (zwarm && vmax > POLISH_WARM_VMAX * (1 + winf)) return 0;
         if (vmax <= es && zmin >= -ez) {
-            if (level == 1 && round + 1 < max_rounds) {
+            if (level == 1 && !p->polish_l1 && round + 1 < max_rounds) {
                 /* verified at the second level: the same active set once more at the first, from these multipliers --
                  * what is left of them to settle are the components that matter (C_A' dz of the size of the rounding of
                  * the second level); the ones that were slow are already in place */

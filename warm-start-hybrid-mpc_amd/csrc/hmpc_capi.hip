@@ -317,6 +317,12 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     p.cs = big > 0 ? 1.0 / big : 1.0;
     for (auto &v : P) v *= p.cs;
     for (auto &v : PT) v *= p.cs;
+    {   // curvature of the (scaled) cost: smallest positive diagonal entry -- decides the penalty level of the polish (DevProb)
+        double cmin = 1.0;
+        for (int i = 0; i < nz; i++) if (P[(size_t)i * nz + i] > 0) cmin = std::fmin(cmin, P[(size_t)i * nz + i]);
+        for (int i = 0; i < nx; i++) if (PT[(size_t)i * nx + i] > 0) cmin = std::fmin(cmin, PT[(size_t)i * nx + i]);
+        p.polish_l1 = cmin >= 1e-2 ? 1 : 0;
+    }
 
     std::vector<int> ei, ej;
     for (int i = 0; i < nz; i++)

@@ -60,6 +60,11 @@ struct DevProb {
     int max_iter, lazy, refine;
     int dbg;                                   // diagnostic build only (HMPC_DBG): phases to skip when timing
     int polish;                                // active-set polish of optimal iterates (hmpc_options.polish)
+    int polish_l1;                             //   1: the polish runs at its second penalty level (1e7) from the start and ends there.  The two levels
+                                               //   exist for costs of tiny curvature (cart-pole: 1.4e-4 after scaling -- eps rho over the curvature is the
+                                               //   accuracy of the vertex, so the first choice there is 1e5 and a set verified at 1e7 goes through 1e5 once more);
+                                               //   with a curvature of order one (smallest positive diagonal entry of the scaled Hessians >= 1e-2) 1e7 gives
+                                               //   1e-9 and the dance between the levels only costs factorisations (configs[4]: 22 % of the polish rounds)
     double ptol;                               //   tried once the scaled residuals and gap are below ptol
 };
 

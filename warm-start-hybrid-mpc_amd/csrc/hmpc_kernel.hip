@@ -45,6 +45,7 @@
 #define HMPC_POLISH_RHO 1e5
 #define HMPC_POLISH_RHO2 1e7 // second level, for active sets whose multiplier steps do not settle at the first
 #define HMPC_POLISH_DELTA 1e-10
+#define HMPC_RHO_OF(level) ((level) == 1 ? HMPC_POLISH_RHO2 : HMPC_POLISH_RHO)
 #define HMPC_POLISH_ITERS 5
 #define HMPC_POLISH_ROUNDS 6
 #define HMPC_POLISH_ROUNDS_LAST 10 // the last attempt, on the iterate the solve would return (round 3, with the rule that every row with a negative multiplier leaves)
@@ -2579,8 +2580,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
     // active set, with factorisation; mode 2: a further multiplier step with the factorisation at hand): the
     // polish reuses the factorisation and the constant-direction solve below instead of owning copies of them.
     int mode = 0, round = 0, al = 0;
-    int level = 0; // penalty of the polish in progress: 0 first level; 1 second; 2 back at the first for the last digits
-#define HMPC_RHO_OF(level) ((level) == 1 ? HMPC_POLISH_RHO2 : HMPC_POLISH_RHO)
+    // penalty of the polish in progress: 0 first level; 1 second; 2 back at the first for the last digits.  p.polish_l1 (a cost
+    // whose curvature is of order one, DevProb): the polish starts at the second level and ends there
+    int level = p.polish_l1;
     double rg = 0, mu = 0, wPw = 0, winf = 0, zinf = 0;
     // PARENT -> CHILD HAND-DOWN (the reference hands the parent's simplex basis to the child: controller.py:260-264,
     // subproblem_solution.py:37-43).  wprim / wdual: the parent's record.  Its active set -- the rows with a positive
@@ -2622,7 +2624,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 else zr = wdual[o_ub + t * nub + (lr - p.nc - nub)] * p.cs;
                 zi = fmax(zi, zr);
                 R.prod(k, rw.e) = 1.0; // the cold start's multiplier, for the way back
-                if (zr > 0.0) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr; }
+                if (zr > 0.0) { d = HMPC_RHO_OF(p.polish_l1); R.dz(k, rw.e) = zr; }
                 else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w); }
                 R.D(k, rw.e) = d;
             }
@@ -2886,14 +2888,14 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 if (zr != 0.0) {
                     const bool active = zr > R.s(k, rw.e) || ((amask >> (k & 63)) & 1ull);
                     R.prod(k, rw.e) = zr; // kept for the way back
-                    if (active) { d = HMPC_POLISH_RHO; R.dz(k, rw.e) = zr / tau; }
+                    if (active) { d = HMPC_RHO_OF(p.polish_l1); R.dz(k, rw.e) = zr / tau; }
                     else { d = HMPC_POLISH_DELTA; R.dz(k, rw.e) = rm.dot(p, S, k, rw, S.w) / tau; }
                     R.D(k, rw.e) = d;
                 }
                 S.e[rw.e] = d;
             ROWS_END
             mode = 1; round = 0; al = 0;
-            level = 0;
+            level = p.polish_l1;
             attempts++;
         } else {
             ROWS_BEGIN(k, rw)
@@ -2999,7 +3001,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                             // verified; at the second level: the same active set once more at the first, from these
                             // multipliers (what is left to settle are the components that matter, of the size of the
                             // second level's rounding; the slow ones are in place)
-                            act = (level == 1 && round + 1 < max_rounds) ? 2 : 0;
+                            act = (level == 1 && !p.polish_l1 && round + 1 < max_rounds) ? 2 : 0;
                         } else if (WARM && warm_try && !own && vmax > HMPC_POLISH_WARM_VMAX * (1 + winf / tau)) {
                             // the handed-down set is not near this node's optimum (the node is infeasible, or fixing the
                             // binary moved the solution): dropped after this one factorisation
