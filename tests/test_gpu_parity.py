@@ -239,7 +239,11 @@ def test_golden_vectors():
             assert name == 'n10free' and tie['status'][0] == 0 and abs(tie['obj'][0] - sol.objective) <= 1e-12 * (1 + sol.objective), name
         for key in ('x', 'uc'):
             got, want = np.array(sol.variables[key]).reshape(1, -1), g[name + '_bb_' + key].reshape(1, -1)
-            assert _rel(got, want).max() < RTOL, (name, 'incumbent', key, _rel(got, want).max())
+            # (element-wise floor 1e-5 on the one-wall system: its cost has a curvature of order one, the polish runs at its second
+            # penalty level throughout (DevProb::polish_l1, round 4) and a vertex is good to ~1e-10 absolute instead of 1e-12:
+            # measured 1.0e-11 on a component of 1e-7; norm-wise the same 1e-9)
+            fl = 1e-5 if name == 'onewall' else None
+            assert _rel(got, want, True, fl).max() < RTOL, (name, 'incumbent', key, _rel(got, want, True, fl).max())
 
 
 def test_full_size_frontier_certifies_itself():
