@@ -299,7 +299,8 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
  *                      form, 2 built-in register kernel, 3 register kernel compiled for this shape.
  *   hmpc_jit_build   : the same compilation ahead of time, without a GPU (kf / kb / kt: row slots of [F G] rows, bound rows
  *                      and terminal rows per lane, ceil(T / floor(64 nw / nc)), ceil(T / floor(64 nw / (2 nub))), max(1,
- *                      ceil(nT / (64 nw))); kc: longest column of the stage rows, rounded up to even). */
+ *                      ceil(nT / (64 nw))); kc: longest column of the stage rows, rounded up to even; nw + 8: the build of the
+ *                      one-wave kernel for two waves per SIMD, which hmpc_create picks where LDS holds six or more nodes per CU). */
 int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3);
 int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len);
 

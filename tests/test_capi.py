@@ -126,7 +126,8 @@ def test_register_kernel_is_compiled_for_an_arbitrary_shape():
     # The reference takes any MLDSystem (warm_start_hmpc/controller.py:58-117); the fast kernel here is a compile-time
     # instantiation.  For a shape without a built-in one hmpc_create compiles it from the same source into an on-disk
     # cache (csrc/hmpc_jit.h); hmpc_jit_build does the same without a GPU.  A random MLD with nx = 6, nu = 2 + 3 -- three
-    # binaries: their six bound rows do not tile a wavefront --: three shared objects (1 / 2 / 4 waves per node), each
+    # binaries: their six bound rows do not tile a wavefront --: four shared objects (1 / 2 / 4 waves per node, the one-wave
+    # kernel also built for two waves per SIMD), each
     # exporting the getter of its two kernels; a second call is a cache hit.
     import time
     from helpers import random_mld, _NoBackend
@@ -137,7 +138,7 @@ def test_register_kernel_is_compiled_for_an_arbitrary_shape():
     shapes = jit_shapes(ctrl.problem_data())
     assert [s[:3] + s[6:] for s in shapes] == [(6, 5, 3, 1, 8), (6, 5, 3, 2, 8), (6, 5, 3, 4, 8)]
     paths = jit_prebuild(ctrl.problem_data())
-    assert len(paths) == 3 and all(os.path.exists(p) for p in paths)
+    assert len(paths) == 4 and all(os.path.exists(p) for p in paths)      # (1 wave: also its build for two waves per SIMD)
     for p in paths:
         assert hasattr(ctypes.CDLL(p), 'hmpc_jit_kernels')
     tic = time.perf_counter()

@@ -170,7 +170,7 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
         if (!hmpc_static_slots(p, 1 << c, kf, kb, kt)) continue;
         if (kt < 1) kt = 1;                 // (the row map keeps a terminal slot; a problem without terminal set leaves it empty)
         if (kf + kb + kt > 16) continue;    // (row state in registers: 4 doubles per slot and lane)
-        shapes[count] = {p.nx, p.nu, p.nub, kf, kb, kt, 1 << c, kc};
+        shapes[count] = {p.nx, p.nu, p.nub, kf, kb, kt, 1 << c, kc, (c == 0 && lds_cu / hmpc_lds_bytes(p, kc, 0) >= 6 && !getenv("HMPC_JIT_NO_OCC2")) ? 1 : 0};
         slot[count++] = c;
     }
     if (!count) return;
@@ -201,10 +201,11 @@ extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
 extern "C" int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len)
 {
     g_err.clear();
-    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 16 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || (nw != 1 && nw != 2 && nw != 4) || kc < 2 ||
+    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 16 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || ((nw & 7) != 1 && (nw & 7) != 2 && (nw & 7) != 4) || (nw & ~15) || kc < 2 ||
         kc > HMPC_KC_STRIDE || (kc & 1))
         return fail(HMPC_EINVAL, "jit: not a shape of the static row map");
-    hmpc_jit_shape s{nx, nu, nub, kf, kb, kt, nw, kc};
+    hmpc_jit_shape s{nx, nu, nub, kf, kb, kt, nw & 7, kc, (nw & 8) ? 1 : 0}; // (nw + 8: the two-waves-per-SIMD build of the one-wave kernel)
+    nw &= 7;
     std::vector<std::string> paths;
     std::string err;
     if (!hmpc_jit_build_all(&s, 1, paths, err) || paths[0].empty()) return fail(HMPC_EDEVICE, "jit: " + err);

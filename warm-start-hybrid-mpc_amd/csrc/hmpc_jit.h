@@ -41,7 +41,13 @@
 
 extern char **environ;
 
-struct hmpc_jit_shape { int nx, nu, nub, kf, kb, kt, nw, kc; };
+struct hmpc_jit_shape {
+    int nx, nu, nub, kf, kb, kt, nw, kc;
+    // two waves per SIMD (256 registers per lane instead of 512): pays where LDS holds more than four nodes per CU -- measured
+    // on a random MLD nx = 6, nu = 2 + 3, N = 12 (26.6 KB of LDS per node, six per CU): 657 k against 547 k QP/s; where only four
+    // fit (nx = 8, nu = 3 + 4, N = 10: 38.4 KB) the spills cost 13 % and buy nothing (tests/gpu_dev_jit_occupancy.py)
+    int occ2 = 0;
+};
 
 namespace hmpc_jit {
 
@@ -90,10 +96,23 @@ inline std::string cache_dir()
     return writable_dir(d) ? d : std::string();
 }
 
+// extra compiler flags of the kernels compiled per shape (part of the cache key), e.g. an occupancy attribute:
+//   HMPC_JIT_FLAGS='-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))'
+inline std::string extra_flags() { const char *e = getenv("HMPC_JIT_FLAGS"); return e ? e : ""; }
+
+inline std::string quoted_flags() // (each blank-separated flag in single quotes: attributes carry parentheses)
+{
+    std::stringstream in(extra_flags());
+    std::string tok, out;
+    while (in >> tok) out += "'" + tok + "' ";
+    return out;
+}
+
 // FNV-1a over the sources a kernel is compiled from: an edit of any of them is another cache entry
 inline uint64_t source_hash()
 {
     uint64_t hsh = 1469598103934665603ull;
+    for (char ch : extra_flags()) { hsh ^= (unsigned char)ch; hsh *= 1099511628211ull; }
     for (const std::string &f : {source_dir() + "/hmpc_kernel.hip", source_dir() + "/hmpc_device.h", include_dir() + "/hmpc.h"}) {
         std::ifstream in(f, std::ios::binary);
         char buf[4096];
@@ -108,7 +127,7 @@ inline uint64_t source_hash()
 inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
 {
     char b[160];
-    snprintf(b, sizeof b, "hmpc_k_%d_%d_%d_%d_%d_%d_w%d_kc%d_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, (unsigned long long)hsh);
+    snprintf(b, sizeof b, "hmpc_k_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "", (unsigned long long)hsh);
     return b;
 }
 
@@ -134,7 +153,7 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
         if (!out) { err = "cannot write " + src; return -1; }
     }
     // the compiler runs as a CHILD process (posix_spawn, as Python's subprocess does): nothing of this process is replaced
-    const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed -I '" + include_dir() + "' -I '" +
+    const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags() + (s.occ2 ? "'-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))' " : "") + " -I '" + include_dir() + "' -I '" +
                             source_dir() + "' -shared -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
     pid_t pid = -1;
     const char *argv[] = {"sh", "-c", cmd.c_str(), nullptr};

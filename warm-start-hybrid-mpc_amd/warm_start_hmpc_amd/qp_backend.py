@@ -172,10 +172,14 @@ def jit_prebuild(problem):
     lib.hmpc_jit_build.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_char_p, ctypes.c_int32]
     paths = []
     for shape in jit_shapes(problem):
-        buf = ctypes.create_string_buffer(1024)
-        if lib.hmpc_jit_build(*shape, buf, 1024) != 0:
-            raise RuntimeError('hmpc_jit_build%r failed: %s' % (shape, lib.hmpc_last_error().decode()))
-        paths.append(buf.value.decode())
+        # (the one-wave kernel also in its build for two waves per SIMD -- nw + 8 --, which hmpc_create picks where LDS holds
+        # six or more nodes per CU)
+        for nw in ((shape[6], shape[6] + 8) if shape[6] == 1 else (shape[6],)):
+            buf = ctypes.create_string_buffer(1024)
+            args = shape[:6] + (nw, shape[7])
+            if lib.hmpc_jit_build(*args, buf, 1024) != 0:
+                raise RuntimeError('hmpc_jit_build%r failed: %s' % (args, lib.hmpc_last_error().decode()))
+            paths.append(buf.value.decode())
     return paths
 
 
