@@ -144,19 +144,19 @@ class _GurobiModel(object):
     def solve(self, x0, fix_row):
         GRB, m, qp = self.GRB, self.m, self.qp
         beq, bin_ = qp.rhs(x0, fix_row)
-        self.ceq.RHS = beq
-        self.cin.RHS = bin_
+        self.ceq.setAttr('RHS', beq)                                  # (explicit attribute calls: documented for MVar / MConstr alike)
+        self.cin.setAttr('RHS', bin_)
         m.optimize()                                                  # (between the nodes of a search the reference keeps the solver's state, too)
         runtime = m.Runtime
         if m.Status == GRB.OPTIMAL:
-            return qp.record(True, np.array(self.w.X), np.array(self.ceq.Pi), np.array(self.cin.Pi), m.ObjVal, beq, bin_), runtime
+            return qp.record(True, np.array(self.w.getAttr('X')), np.array(self.ceq.getAttr('Pi')), np.array(self.cin.getAttr('Pi')), m.ObjVal, beq, bin_), runtime
         m.setObjective(0.0)
         m.Params.InfUnbdInfo = 1
         m.optimize()
         runtime += m.Runtime
         if m.Status != GRB.INFEASIBLE:
             raise AssertionError('The problem seems to be unbounded.')   # (the reference's words, bounded_qp.py:221)
-        out = qp.record(False, None, np.array(self.ceq.FarkasDual), np.array(self.cin.FarkasDual), np.inf, beq, bin_)
+        out = qp.record(False, None, np.array(self.ceq.getAttr('FarkasDual')), np.array(self.cin.getAttr('FarkasDual')), np.inf, beq, bin_)
         m.setMObjective(qp.Hq, None, 0.0, sense=GRB.MINIMIZE)
         return out, runtime
 
