@@ -63,10 +63,14 @@ inline std::string dir_of_library()
 
 inline bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
+// A cache directory is code that gets loaded: it must be a directory of THIS user that nobody else can write to.
 inline bool writable_dir(const std::string &d)
 {
     if (d.empty()) return false;
     (void)mkdir(d.c_str(), 0755);
+    struct stat st;
+    if (stat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    if (st.st_uid != geteuid() || (st.st_mode & (S_IWGRP | S_IWOTH))) return false;
     return access(d.c_str(), W_OK | X_OK) == 0;
 }
 
@@ -92,7 +96,7 @@ inline std::string cache_dir()
         d = std::string(h) + "/.cache/hmpc_amd";
         if (writable_dir(d)) return d;
     }
-    d = "/tmp/hmpc_amd_jit";
+    d = "/tmp/hmpc_amd_jit_" + std::to_string((unsigned long)geteuid()); // (per user; refused above unless it is this user's alone)
     return writable_dir(d) ? d : std::string();
 }
 
