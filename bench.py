@@ -284,9 +284,21 @@ def other_configs(dev):
     r, _ = _device_rate(c4.qp, x0, f, dev, reps=3, warm=1)
     r['algorithmic_bytes_per_qp'] = c4.layout.bytes_per_qp()
     r['achieved_GBs'] = r['algorithmic_bytes_per_qp'] * r['nodes'] / (r['kernel_ms_avg'] * 1e-3) / 1e9
-    r['kernel'] = 'hmpc_qp_kernel<-1,...> (generic, streaming form: factor in a global slab; panel elimination on wave 0, tiles on the matrix cores)'
+    r['kernel'] = ('hmpc_qp_kernel<-1,...> (generic, streaming form: factor in a global slab; panel elimination on wave 0, tiles on the matrix cores), '
+                   'compiled with this problem\'s sizes at hmpc_create (csrc/hmpc_jit.h)')
+    r['kernel_kinds'] = list(c4.qp.kernel_info())
     r['frontier'] = '4096 distinct nodes: prefixes of a dive to a feasible leaf, every other one with one binary flipped (random prefixes of this generator are all infeasible)'
     out['random_mld_nx20_nu14_N30_dive_frontier_4096'] = r
+    # the same launch on the shipped run-time-sized build of the streaming form (what served the problem until round 4)
+    os.environ['HMPC_JIT_SIZED'] = '0'
+    try:
+        plain = HipBatchedQP(c4.problem_data())
+    finally:
+        del os.environ['HMPC_JIT_SIZED']
+    r, _ = _device_rate(plain, x0, f, dev, reps=2, warm=1)
+    r['kernel_kinds'] = list(plain.kernel_info())
+    out['random_mld_nx20_nu14_N30_dive_frontier_4096_run_time_sized_kernel'] = r
+    del plain
     # the same problem with the parent -> child hand-down (hmpc_warm): the tree a dive leaves behind (prefix chain of the
     # leaf + one-flip siblings, 481 nodes, every node but the root with its parent in the frontier), tiled to 4096; the
     # parents' records come from one untimed cold pass (as replay_frontier_4096_handdown on the headline system)

@@ -295,14 +295,21 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
  * warm_start_hmpc/controller.py:58-117 -- from the sources next to the library, with the offline compiler, into an on-disk
  * cache (csrc/hmpc_jit.h: requirements, environment HMPC_JIT / HMPC_JIT_CACHE / HMPC_HIPCC); shapes outside the static row
  * map's reach, or hosts without a compiler, are served by the run-time-sized kernel.
+ * Problems the static row map does not hold (or too large for one CU's LDS) run the run-time-sized kernel / its streaming form
+ * COMPILED WITH THE PROBLEM'S SIZES as constants, by the same mechanism (HMPC_JIT_SIZED=0: the shipped kernel): the same
+ * code paths, 1.4x on BASELINE configs[4].
  *   hmpc_kernel_info : which kernel serves the problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming
- *                      form, 2 built-in register kernel, 3 register kernel compiled for this shape.
+ *                      form, 2 built-in register kernel, 3 register kernel compiled for this shape, 4 / 5 the run-time-sized
+ *                      kernel / its streaming form compiled with this problem's sizes.
+ *   hmpc_jit_build_problem : everything hmpc_create would compile for this problem, ahead of time and without a GPU (the host
+ *                      side of hmpc_create, nothing uploaded); paths: the shared objects, newline separated (may be NULL).
  *   hmpc_jit_build   : the same compilation ahead of time, without a GPU (kf / kb / kt: row slots of [F G] rows, bound rows
  *                      and terminal rows per lane, ceil(T / floor(64 nw / nc)), ceil(T / floor(64 nw / (2 nub))), max(1,
  *                      ceil(nT / (64 nw))); kc: longest column of the stage rows, rounded up to even; nw + 8: the build of the
  *                      one-wave kernel for two waves per SIMD, which hmpc_create picks where LDS holds six or more nodes per CU). */
 int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3);
 int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len);
+int hmpc_jit_build_problem(const hmpc_problem *problem, const hmpc_options *options, char *paths, int32_t paths_len);
 
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);

@@ -1,0 +1,39 @@
+"""The problems of the test suite and of bench.py whose kernels ``hmpc_create`` compiles at first use (csrc/hmpc_jit.h):
+register kernels for shapes without a built-in instantiation, the run-time-sized kernel with the problem's sizes where the
+static row map does not hold the problem.  ``prewarm()`` compiles them into the cache ahead of time, without a GPU
+(``jit_prebuild``) -- ``__graft_entry__.build()`` calls it, so that a GPU box (which has the compiler too) meets cache hits:
+
+    python tests/jit_problems.py
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa: F401  (puts the package on the path)
+from helpers import random_mld, _NoBackend
+
+# (nx, nuc, nub, seed, T): random MLDs of helpers.random_mld
+REGISTER_SHAPES = ((6, 2, 3, 3, 8), (6, 2, 3, 3, 12), (8, 3, 4, 2, 10))
+SIZED = ((20, 6, 8, 0, 30),       # BASELINE configs[4]: beyond one CU's LDS, the streaming form
+         (10, 4, 4, 5, 8))        # nx + nu = 18: beyond the static row map, fits LDS (1 / 2 / 4 waves per node)
+
+
+def problem(nx, nuc, nub, seed, T):
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
+    return HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend()).problem_data(), mld, objective, x0
+
+
+def prewarm(verbose=False):
+    from warm_start_hmpc_amd.qp_backend import jit_prebuild
+    paths = []
+    for spec in REGISTER_SHAPES + SIZED:
+        got = jit_prebuild(problem(*spec)[0])
+        if verbose:
+            print(spec, [os.path.basename(p) for p in got])
+        paths += got
+    return paths
+
+
+if __name__ == '__main__':
+    prewarm(verbose=True)

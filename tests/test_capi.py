@@ -146,3 +146,26 @@ def test_register_kernel_is_compiled_for_an_arbitrary_shape():
     # shapes the static row map does not hold, and the built-in ones, are not compiled
     big = HybridModelPredictiveController(random_mld()[0], 30, random_mld()[1], None, backend=_NoBackend())
     assert jit_shapes(big.problem_data()) == []
+
+
+def test_run_time_sized_kernel_is_compiled_with_the_sizes_of_a_problem():
+    # Problems the static row map does not hold run the run-time-sized kernel (or, beyond one CU's LDS, its streaming form)
+    # COMPILED WITH THEIR SIZES as constants -- same source, same code paths, hmpc_jit.h; 1.4x on BASELINE configs[4].
+    # hmpc_jit_build_problem runs the host side of hmpc_create without a GPU: configs[4] gets the streaming form for four
+    # waves per node (the only wave count that form runs), a random MLD with nx + nu = 18 the kernel for 1 / 2 / 4 waves.
+    import time
+    from jit_problems import problem, SIZED
+    from warm_start_hmpc_amd.qp_backend import jit_prebuild
+    for spec, names in zip(SIZED, (['hmpc_s_stream_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'])):
+        data = problem(*spec)[0]
+        paths = jit_prebuild(data)
+        assert [os.path.basename(p)[:len(n)] for p, n in zip(paths, names)] == names and len(paths) == len(names), paths
+        for p in paths:
+            lib = ctypes.CDLL(p)
+            assert hasattr(lib, 'hmpc_jit_kernels')
+            lib.hmpc_jit_sized.restype = ctypes.c_char_p
+            fields = lib.hmpc_jit_sized().decode()
+            nx, nuc, nub, _, T = spec
+            assert ('p.nx=%d;p.nu=%d;p.nub=%d;' % (nx, nuc + nub, nub)) in fields and ('p.T=%d;' % T) in fields
+        tic = time.perf_counter()
+        assert jit_prebuild(data) == paths and time.perf_counter() - tic < 2.0                    # (cache hits)

@@ -409,6 +409,52 @@ def test_register_kernel_compiled_for_an_arbitrary_shape():
         np.testing.assert_allclose(g['obj'][fin], a['obj'][fin], rtol=1e-8, atol=1e-11)
 
 
+def test_sized_kernels_of_a_problem_beyond_the_static_row_map():
+    # nx + nu = 18: no register kernel (the static row map ends at 16), the problem fits one CU's LDS -- the run-time-sized
+    # kernel compiled with the problem's sizes serves 1 / 2 / 4 waves per node (csrc/hmpc_jit.h, round 4).  Same records as
+    # the oracle at the one tolerance, and as the shipped run-time-sized kernel (HMPC_JIT_SIZED=0).
+    from jit_problems import problem, SIZED
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    nx, nuc, nub, seed, T = SIZED[1]
+    data, mld, objective, x0 = problem(*SIZED[1])
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    hip, orc = HipBatchedQP(data), OracleBatchedQP(data, threads=8)
+    assert hip.kernel_info() == (4, 4, 4), hip.kernel_info()
+    os.environ['HMPC_JIT_SIZED'] = '0'
+    try:
+        plain = HipBatchedQP(data)
+    finally:
+        del os.environ['HMPC_JIT_SIZED']
+    assert plain.kernel_info() == (0, 0, 0)
+    Cj = np.array([mld.F[2 * nx + 2 * nuc + 4 * j] for j in range(nub)])
+    leaf = np.full((1, T * nub), -1, np.int8)
+    for t in range(T):
+        r = orc.solve_batch(x0, leaf)
+        leaf[0, t * nub:(t + 1) * nub] = (r['primal'][0][:(T + 1) * nx].reshape(T + 1, nx)[t] @ Cj.T >= 0)
+    rng = np.random.default_rng(seed)
+    fix = np.concatenate((random_prefix_frontier(T, nub, 64, p_one=0.3), np.full((96, T * nub), -1, np.int8)))
+    for k in range(65, 160):
+        d = int(rng.integers(1, T * nub + 1))
+        fix[k, :d] = leaf[0, :d]
+        if k % 2 == 0:
+            j = int(rng.integers(0, d))
+            fix[k, j] = 1 - fix[k, j]
+    b = orc.solve_batch(x0, fix)
+    assert (b['status'] == 0).sum() >= 20 and (b['status'] == 1).sum() >= 20
+    for waves in ('1', '2', '4'):
+        os.environ['HMPC_WAVES'] = waves
+        try:
+            a, c = hip.solve_batch(x0, fix), plain.solve_batch(x0, fix)
+        finally:
+            del os.environ['HMPC_WAVES']
+        _compare(ctrl, a, b, T, fix, min_polished=0.99, x0=x0, efloor=1e-5)
+        assert np.array_equal(c['status'], a['status'])
+        fin = a['status'] == 0
+        np.testing.assert_allclose(c['obj'][fin], a['obj'][fin], rtol=1e-9, atol=1e-12)
+
+
 def test_two_launch_form_of_the_lazy_terminal_set(monkeypatch):
     # Opt-in (HMPC_SPLIT=1): large cold batches leave the nodes that need the terminal-set rows to a second launch (four
     # waves per node, each from its own first record: hmpc_capi.hip, DevWarm).  Same statuses and the same vertices as the
@@ -488,6 +534,20 @@ def test_streaming_kernel_baseline_config4():
     orc.threads = os.cpu_count() or 8
     a, b = hip.solve_batch(x0, fix), orc.solve_batch(x0, fix)
     assert hip.launch_info()[1] > 100 * 1024          # the streaming carve: vectors only, still most of a CU
+    # round 4: the kernel that runs is the streaming form COMPILED WITH THIS PROBLEM'S SIZES (csrc/hmpc_jit.h; four waves per
+    # node, the only wave count that form runs); the shipped run-time-sized build (HMPC_JIT_SIZED=0) returns the same records
+    assert hip.kernel_info() == (1, 1, 5), hip.kernel_info()
+    os.environ['HMPC_JIT_SIZED'] = '0'
+    try:
+        plain = HipBatchedQP(ctrl.problem_data())
+    finally:
+        del os.environ['HMPC_JIT_SIZED']
+    assert plain.kernel_info() == (1, 1, 1)
+    c = plain.solve_batch(x0, fix[:512])
+    assert np.array_equal(c['status'], a['status'][:512]) and np.array_equal(c['polished'] > 0, a['polished'][:512] > 0)
+    fin = c['status'] == 0
+    np.testing.assert_allclose(c['obj'][fin], a['obj'][:512][fin], rtol=1e-9, atol=1e-12)
+    assert np.max(np.abs(c['primal'][fin][:, :(T + 1) * nx] - a['primal'][:512][fin][:, :(T + 1) * nx])) < 1e-8
     # this generator leaves the binaries out of the cost (R = [I 0], as the reference does): states and continuous
     # inputs are unique and compared at RTOL like everywhere else, the relaxed binaries are not.  Every record at the one
     # tolerance; >= 99 % of the optimal nodes polished (measured: all of them, on both sides -- the tolerance escalation

@@ -37,10 +37,12 @@ struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve
     hmpc_kernel_choice k{};
     size_t lds = 0;
     int max_grid = 0;
+    int sized = 0; // k is the run-time-sized kernel compiled with this problem's sizes (hmpc_jit_prepare_sized)
 };
 
 struct hmpc_handle {
     int device = 0;
+    bool dry = false; // hmpc_jit_build_problem: the host side of hmpc_create without a device (nothing uploaded, nothing launched)
     hmpc_cfg cfg[3];
     DevProb dp{};
     std::vector<void *> allocs;
@@ -126,6 +128,7 @@ template <class T>
 int upload(hmpc_handle *h, const std::vector<T> &v, const T **out)
 {
     void *d = nullptr;
+    if (h->dry) { *out = nullptr; return HMPC_OK; }
     const size_t bytes = (v.size() ? v.size() : 1) * sizeof(T);
     HIPCHK(hipMalloc(&d, bytes));
     h->allocs.push_back(d);
@@ -156,7 +159,7 @@ int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
 // Register kernels of this problem's shape for 1 / 2 / 4 waves per node, compiled or fetched from the cache (hmpc_jit.h).
 // Shapes with a built-in instantiation, shapes the static row map does not hold, and hosts without a compiler leave jit
 // empty: hmpc_pick_kernel then takes what it always took.
-void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu)
+void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu, std::vector<std::string> *built)
 {
     if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return;
     if ((p.nx == 4 && p.nu == 7 && p.nub == 4) || (p.nx == 4 && p.nu == 4 && p.nub == 2)) return; // (built in)
@@ -179,6 +182,11 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
     (void)hmpc_jit_build_all(shapes, count, paths, err);
     for (int i = 0; i < count; i++) {
         if (paths[i].empty()) continue;
+        if (built) {                                                     // (dry run: built, not loaded; the choice of kernels must still see it)
+            built->push_back(paths[i]);
+            jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0};
+            continue;
+        }
         void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) { err = std::string("dlopen: ") + dlerror(); continue; }
         auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
@@ -189,6 +197,64 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
         jit[slot[i]] = {(hmpc_kernel_t)cold, (hmpc_kernel_t)warm, shapes[i].nw, kc, 0};
     }
     if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: register kernel for this shape not available (%s): the run-time-sized kernel serves it\n", err.c_str());
+}
+
+// The integer sizes of a problem as assignments to the fields of DevProb: the body of HMPC_SIZED(p) of a kernel compiled for
+// this problem alone (hmpc_jit.h), and with it the key of its cache entry.  Everything the kernels read as an int that is
+// fixed once the problem is: dimensions, row counts and their splits, list lengths, the magic numbers of the divisions,
+// the LDS choices of hmpc_create.  Tolerances, options and pointers stay arguments.
+std::string hmpc_sized_fields(const DevProb &p)
+{
+    char b[1024];
+    snprintf(b, sizeof b,
+             "p.nx=%d;p.nu=%d;p.nub=%d;p.nuc=%d;p.nz=%d;p.T=%d;p.nc=%d;p.ncL=%d;p.nT=%d;p.mreg=%d;p.Toff=%d;p.M=%d;p.Mpad=%d;p.n=%d;p.ne=%d;"
+             "p.nq=%d;p.nr=%d;p.nqT=%d;p.n_primal=%d;p.n_dual=%d;p.mreg_magic=%uu;p.nnz0=%d;p.nng0=%d;p.reg.m=%d;p.reg.mg=%d;p.kcol=%d;p.ngram=%d;"
+             "p.ring=%d;p.nd=%d;p.ndp=%d;p.ns=%d;p.nd_magic=%uu;p.nn_magic=%uu;p.split_lds=%d;p.static_rows=%d;p.polish_l1=%d;",
+             p.nx, p.nu, p.nub, p.nuc, p.nz, p.T, p.nc, p.ncL, p.nT, p.mreg, p.Toff, p.M, p.Mpad, p.n, p.ne, p.nq, p.nr, p.nqT, p.n_primal, p.n_dual,
+             p.mreg_magic, p.nnz0, p.nng0, p.reg.m, p.reg.mg, p.kcol, p.ngram, p.ring, p.nd, p.ndp, p.ns, p.nd_magic, p.nn_magic, p.split_lds,
+             p.static_rows, p.polish_l1);
+    return b;
+}
+
+// Sized kernels (hmpc_jit.h) for the wave counts of this problem that the run-time-sized kernel or its streaming form would
+// serve: compiled or fetched from the cache, they replace it in `cfg`.  The streaming form runs four waves per node
+// whatever the batch (hmpc_solve_batch_device), so only that one is built.  HMPC_JIT_SIZED=0: none.
+void hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<void *> &libs, int &count_out, std::vector<std::string> *built)
+{
+    if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return; // (the run-time-sized kernels themselves are asked for)
+    if (const char *e = getenv("HMPC_JIT_SIZED")) { if (atoi(e) == 0) return; }
+    const std::string fields = hmpc_sized_fields(p);
+    hmpc_jit_shape shapes[3];
+    int slot[3], count = 0;
+    int only = -1;
+    if (const char *e = getenv("HMPC_WAVES")) { const int nw = atoi(e); only = nw == 1 ? 0 : nw == 2 ? 1 : nw == 4 ? 2 : -1; }
+    for (int c = 0; c < 3; c++) {
+        if (cfg[c].k.kc > 0) continue;                                   // a register kernel serves this wave count
+        if (cfg[c].k.big && c != (only >= 0 ? only : 2)) continue;
+        shapes[count] = hmpc_jit_shape{cfg[c].k.big ? -1 : 0, -1, 0, 0, 0, 0, 1 << c, 0, 0, fields};
+        slot[count++] = c;
+    }
+    if (!count) return;
+    std::vector<std::string> paths;
+    std::string err;
+    (void)hmpc_jit_build_all(shapes, count, paths, err);
+    for (int i = 0; i < count; i++) {
+        if (paths[i].empty()) continue;
+        if (built) { built->push_back(paths[i]); continue; }           // (dry run: built, not loaded)
+        void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!lib) { err = std::string("dlopen: ") + dlerror(); continue; }
+        auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
+        auto what = (const char *(*)(void))dlsym(lib, "hmpc_jit_sized");
+        if (!get || !what || fields != what()) { err = "not the kernel of this problem: " + paths[i]; continue; } // (a collision of the key's hash)
+        void *cold = nullptr, *warm = nullptr;
+        get(&cold, &warm);
+        libs.push_back(lib);
+        cfg[slot[i]].k.fn = (hmpc_kernel_t)cold;
+        cfg[slot[i]].k.fn_warm = (hmpc_kernel_t)warm;
+        cfg[slot[i]].sized = 1;
+        count_out++;
+    }
+    if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: sized kernel for this problem not available (%s): the run-time-sized kernel serves it\n", err.c_str());
 }
 
 } // namespace
@@ -213,10 +279,13 @@ extern "C" int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, i
     return HMPC_OK;
 }
 
-extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out)
+// hmpc_create; with `built` the DRY form behind hmpc_jit_build_problem: the same host code up to the choice of kernels --
+// which compiles what this problem's kernels need into the cache -- without a device: nothing is uploaded, no handle returned.
+static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out, std::vector<std::string> *built)
 {
     g_err.clear();
-    if (!q || !out) return fail(HMPC_EINVAL, "null problem or output pointer");
+    const bool dry = built != nullptr;
+    if (!q || (!out && !dry)) return fail(HMPC_EINVAL, "null problem or output pointer");
     if (q->nx < 1 || q->nu < 1 || q->nub < 0 || q->nub > q->nu || q->T < 2 || q->nc < 0 || q->ncT < q->nc ||
         q->nq < 0 || q->nr < 0 || q->nqT < 0)
         return fail(HMPC_EINVAL, "inconsistent sizes (need nx,nu >= 1, 0 <= nub <= nu, T >= 2, ncT >= nc)");
@@ -224,12 +293,15 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         return fail(HMPC_EINVAL, "null matrix pointer");
 
     hmpc_handle *h = new hmpc_handle();
+    h->dry = dry;
     int dev = opt ? opt->device : -1;
-    if (dev < 0) {
-        if (hipGetDevice(&dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "no HIP device available"); }
+    if (!dry) {
+        if (dev < 0) {
+            if (hipGetDevice(&dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "no HIP device available"); }
+        }
+        h->device = dev;
+        if (hipSetDevice(dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "hipSetDevice failed"); }
     }
-    h->device = dev;
-    if (hipSetDevice(dev) != hipSuccess) { delete h; return fail(HMPC_EDEVICE, "hipSetDevice failed"); }
 
     DevProb &p = h->dp;
     const int nx = q->nx, nu = q->nu, nz = q->nx + q->nu;
@@ -416,8 +488,10 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
 
     // launch geometry: one 64-lane workgroup per node in flight, as many per CU as LDS admits
     int cus = 0, lds_max = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    if (!dry) {
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+    }
     const size_t lds_cu = 160 * 1024;
     if (p.M >= 65536 || p.mreg >= 65536) { hmpc_destroy(h); return fail(HMPC_ETOOBIG, "more than 65535 constraint rows per node"); }
     // generic kernel on the matrix cores (nz >= 16): the dense stage rows go to LDS if they fit beside everything else
@@ -439,7 +513,7 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     }
     // shapes without a built-in instantiation: the register kernel is compiled now (or found in the cache), hmpc_jit.h
     hmpc_kernel_choice jit[3] = {};
-    hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu);
+    hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu, built);
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
     for (int c = 0; c < 3; c++) {
@@ -448,10 +522,16 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
         cf.lds = hmpc_lds_bytes(p, cf.k.kc, cf.k.big);
         if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
             char msg[256];
-            snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max);
+            snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max > 0 ? lds_max : (int)lds_cu);
             hmpc_destroy(h);
             return fail(HMPC_ETOOBIG, msg);
         }
+    }
+    // wave counts left to the run-time-sized kernel: that kernel compiled with this problem's sizes (or found in the cache)
+    hmpc_jit_prepare_sized(p, h->cfg, h->jit_libs, h->jit_kernels, built);
+    if (dry) { delete h; return HMPC_OK; }
+    for (int c = 0; c < 3; c++) {
+        hmpc_cfg &cf = h->cfg[c];
         if (hipFuncSetAttribute((const void *)cf.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess ||
             hipFuncSetAttribute((const void *)cf.k.fn_warm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess) {
             hmpc_destroy(h);
@@ -494,9 +574,28 @@ extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_
     return HMPC_OK;
 }
 
+extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out) { return create_impl(q, opt, out, nullptr); }
+
+// What hmpc_create would compile for this problem -- the register kernels of its shape, or the run-time-sized kernel with
+// its sizes (hmpc_jit.h) --, compiled into the cache WITHOUT a GPU: packaging, or warming the cache of a machine without a
+// compiler from one that has it.  paths (may be NULL): the shared objects, newline separated.
+extern "C" int hmpc_jit_build_problem(const hmpc_problem *q, const hmpc_options *opt, char *paths, int32_t paths_len)
+{
+    std::vector<std::string> built;
+    const int rc = create_impl(q, opt, nullptr, &built);
+    if (rc != HMPC_OK) return rc;
+    if (paths && paths_len > 0) {
+        std::string all;
+        for (const std::string &b : built) all += b + "\n";
+        snprintf(paths, (size_t)paths_len, "%s", all.c_str());
+    }
+    return HMPC_OK;
+}
+
 extern "C" int hmpc_destroy(hmpc_handle *h)
 {
     if (!h) return HMPC_OK;
+    if (h->dry) { delete h; return HMPC_OK; }
     (void)hipSetDevice(h->device);
     for (void *d : h->allocs) (void)hipFree(d);
     if (h->rows_ws) (void)hipFree(h->rows_ws);
@@ -511,7 +610,8 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
 }
 
 // Which kind of kernel serves this problem, per waves per node (1, 2, 4): 0 run-time-sized, 1 its streaming form,
-// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create.
+// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create, 4 / 5 the run-time-sized kernel /
+// its streaming form compiled with this problem's sizes at hmpc_create.
 extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
 {
     if (!h || !kind3) return fail(HMPC_EINVAL, "null argument");
@@ -524,7 +624,7 @@ extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
             if (get) get(&a, &b);
             jitted |= a == (void *)k.fn;
         }
-        kind3[c] = k.kc > 0 ? (jitted ? 3 : 2) : k.big ? 1 : 0;
+        kind3[c] = k.kc > 0 ? (jitted ? 3 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
     }
     return HMPC_OK;
 }

@@ -47,6 +47,11 @@ struct hmpc_jit_shape {
     // on a random MLD nx = 6, nu = 2 + 3, N = 12 (26.6 KB of LDS per node, six per CU): 657 k against 547 k QP/s; where only four
     // fit (nx = 8, nu = 3 + 4, N = 10: 38.4 KB) the spills cost 13 % and buy nothing (tests/gpu_dev_jit_occupancy.py)
     int occ2 = 0;
+    // SIZED kernel (round 4): the run-time-sized kernel (nx = 0) or its streaming form (nx = -1) compiled with the integer
+    // sizes of ONE problem as constants -- `sized` is the body of the HMPC_SIZED(p) macro, assignments to the fields of DevProb
+    // (hmpc_sized_fields in hmpc_capi.hip); nu = -1 marks the instantiation (its symbols differ from the shipped kernels').
+    // The same code paths with immediates for strides, trip counts and divisions: configs[4] 1.4x.
+    std::string sized;
 };
 
 namespace hmpc_jit {
@@ -128,9 +133,20 @@ inline uint64_t source_hash()
     return hsh;
 }
 
+inline uint64_t fnv(const std::string &t)
+{
+    uint64_t hsh = 1469598103934665603ull;
+    for (char ch : t) { hsh ^= (unsigned char)ch; hsh *= 1099511628211ull; }
+    return hsh;
+}
+
 inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
 {
     char b[160];
+    if (!s.sized.empty()) {
+        snprintf(b, sizeof b, "hmpc_s_%s_w%d_%016llx_%016llx", s.nx < 0 ? "stream" : "generic", s.nw, (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
+        return b;
+    }
     snprintf(b, sizeof b, "hmpc_k_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "", (unsigned long long)hsh);
     return b;
 }
@@ -149,6 +165,12 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
     const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp.so";
     {
         std::ofstream out(src);
+        if (!s.sized.empty())
+            out << "// generated by hmpc_jit.h: the run-time-sized kernel with the sizes of one problem as constants\n#define HMPC_KERNEL_ONLY\n#define HMPC_SIZED(p) " << s.sized
+                << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<"
+                << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ", true>;\n}\nextern \"C\" const char *hmpc_jit_sized(void) { return \""
+                << s.sized << "\"; }\n";
+        else
         out << "// generated by hmpc_jit.h: the register kernel of one problem shape\n#define HMPC_KERNEL_ONLY\n#define HMPC_JIT_KC " << s.kc
             << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", " << s.nu << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", "
             << s.kt << ", " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<" << s.nx << ", " << s.nu

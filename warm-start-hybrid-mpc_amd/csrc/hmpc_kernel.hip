@@ -3437,10 +3437,19 @@ DEV void write_record(const DevProb &p, const Lds &S, int lane, int status, doub
 // compile-time shapes; all zero for the generic kernel (list row map, rows in the global slab).
 template <int NX_, int NU_, int NUB_, int KF, int KB, int KT, int NW, bool WARM = false>
 __global__ void __launch_bounds__(NW * WAVE) HMPC_KERNEL_ATTR
-hmpc_qp_kernel(const DevProb p, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
+hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B,
                const DevOut out, double *__restrict__ rows_ws, double *__restrict__ trace, const int32_t *__restrict__ order, const DevWarm warm)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef HMPC_SIZED
+    // A kernel compiled for ONE problem (hmpc_jit.h): the integer sizes of DevProb are constants of the translation unit --
+    // the same code paths with immediates for strides, trip counts and divisions (time of the run-time-sized kernels is the
+    // instruction count of wave 0).  The host launches it only with the DevProb the constants were taken from.
+    DevProb p = p_arg;
+    HMPC_SIZED(p)
+#else
+    const DevProb &p = p_arg;
+#endif
     constexpr int RS = KF + KB + KT;
     typedef Dims<NX_, NU_, NUB_, NW, (RS > 0 && RS <= 8)> D;
     static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernels the lists");

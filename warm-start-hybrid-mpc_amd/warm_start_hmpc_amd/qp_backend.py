@@ -128,12 +128,32 @@ def load_library():
     return _lib
 
 
-EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_build',
+EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_build', 'hmpc_jit_build_problem',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_stop', 'hmpc_fleet_rows', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
                     'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_allreduce_incumbent_device', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
+
+
+def _problem_struct(problem):
+    """``hmpc_problem`` of a ``problem_data()`` dict, and the arrays it points into (to be kept alive by the caller)."""
+    keep = {}
+    for k in ('A', 'B', 'F', 'G', 'F_Tm1', 'G_Tm1', 'Q', 'R', 'Q_T'):
+        keep[k] = np.ascontiguousarray(np.atleast_2d(problem[k]), dtype=np.float64)
+    for k in ('h', 'h_Tm1'):
+        keep[k] = np.ascontiguousarray(problem[k], dtype=np.float64).reshape(-1)
+    nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
+    shapes = {'A': (nx, nx), 'B': (nx, nu), 'F': (keep['h'].size, nx), 'G': (keep['h'].size, nu),
+              'F_Tm1': (keep['h_Tm1'].size, nx), 'G_Tm1': (keep['h_Tm1'].size, nu),
+              'Q': (keep['Q'].shape[0], nx), 'R': (keep['R'].shape[0], nu), 'Q_T': (keep['Q_T'].shape[0], nx)}
+    for k, shp in shapes.items():
+        if keep[k].shape != shp:
+            raise ValueError('Matrix %s has shape %s, expected %s.' % (k, keep[k].shape, shp))
+    p = _Problem(nx=nx, nu=nu, nub=nub, T=T, nc=keep['h'].size, ncT=keep['h_Tm1'].size,
+                 nq=keep['Q'].shape[0], nr=keep['R'].shape[0], nqT=keep['Q_T'].shape[0],
+                 **{k: v.ctypes.data_as(_dp) for k, v in keep.items()})
+    return p, keep
 
 
 def jit_shapes(problem):
@@ -165,11 +185,21 @@ def jit_shapes(problem):
 
 
 def jit_prebuild(problem):
-    """Compiles (or finds in the cache) the register kernels ``hmpc_create`` would compile for ``problem`` -- without a GPU
-    (``hmpc_jit_build``).  Returns the paths of the shared objects."""
+    """Compiles (or finds in the cache) what ``hmpc_create`` would compile for ``problem`` -- without a GPU: the register
+    kernels of its shape (``hmpc_jit_build``, incl. the two-waves-per-SIMD build of the one-wave kernel, whichever of the
+    two ``hmpc_create`` picks), or -- where the static row map does not hold the problem -- the run-time-sized kernel with the
+    problem's sizes (``hmpc_jit_build_problem``).  Returns the paths of the shared objects."""
     lib = load_library()
     lib.hmpc_jit_build.restype = ctypes.c_int
     lib.hmpc_jit_build.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_char_p, ctypes.c_int32]
+    lib.hmpc_jit_build_problem.restype = ctypes.c_int
+    lib.hmpc_jit_build_problem.argtypes = [ctypes.POINTER(_Problem), ctypes.POINTER(_Options), ctypes.c_char_p, ctypes.c_int32]
+    if not jit_shapes(problem):
+        p, keep = _problem_struct(problem)
+        buf = ctypes.create_string_buffer(8192)
+        if lib.hmpc_jit_build_problem(ctypes.byref(p), None, buf, 8192) != 0:
+            raise RuntimeError('hmpc_jit_build_problem failed: %s' % lib.hmpc_last_error().decode())
+        return [q for q in buf.value.decode().split('\n') if q]
     paths = []
     for shape in jit_shapes(problem):
         # (the one-wave kernel also in its build for two waves per SIMD -- nw + 8 --, which hmpc_create picks where LDS holds
@@ -229,22 +259,9 @@ class HipBatchedQP(object):
                  polish=True, polish_tol=1e-4):
         self.lib = load_library()
         self.device = int(device)
-        keep = {}
-        for k in ('A', 'B', 'F', 'G', 'F_Tm1', 'G_Tm1', 'Q', 'R', 'Q_T'):
-            keep[k] = np.ascontiguousarray(np.atleast_2d(problem[k]), dtype=np.float64)
-        for k in ('h', 'h_Tm1'):
-            keep[k] = np.ascontiguousarray(problem[k], dtype=np.float64).reshape(-1)
-        nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
-        shapes = {'A': (nx, nx), 'B': (nx, nu), 'F': (keep['h'].size, nx), 'G': (keep['h'].size, nu),
-                  'F_Tm1': (keep['h_Tm1'].size, nx), 'G_Tm1': (keep['h_Tm1'].size, nu),
-                  'Q': (keep['Q'].shape[0], nx), 'R': (keep['R'].shape[0], nu), 'Q_T': (keep['Q_T'].shape[0], nx)}
-        for k, shp in shapes.items():
-            if keep[k].shape != shp:
-                raise ValueError('Matrix %s has shape %s, expected %s.' % (k, keep[k].shape, shp))
+        p, keep = _problem_struct(problem)
+        nx, nu, nub, T = p.nx, p.nu, p.nub, p.T
         self._keep = keep
-        p = _Problem(nx=nx, nu=nu, nub=nub, T=T, nc=keep['h'].size, ncT=keep['h_Tm1'].size,
-                     nq=keep['Q'].shape[0], nr=keep['R'].shape[0], nqT=keep['Q_T'].shape[0],
-                     **{k: v.ctypes.data_as(_dp) for k, v in keep.items()})
         o = _Options(tol=tol, tol_inf=tol_inf, max_iter=int(max_iter), lazy_terminal=int(bool(lazy_terminal)),
                      refine=int(bool(refine)), device=int(device), polish=int(bool(polish)), reserved=0,
                      polish_tol=float(polish_tol))
@@ -342,7 +359,8 @@ class HipBatchedQP(object):
 
     def kernel_info(self):
         """Kind of kernel that serves this problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming form,
-        2 built-in register kernel, 3 register kernel compiled for this shape at creation (``hmpc_kernel_info``)."""
+        2 built-in register kernel, 3 register kernel compiled for this shape at creation, 4 / 5 the run-time-sized kernel /
+        its streaming form compiled with this problem's sizes at creation (``hmpc_kernel_info``)."""
         k = (ctypes.c_int32 * 3)()
         self.lib.hmpc_kernel_info.restype = ctypes.c_int
         self.lib.hmpc_kernel_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
