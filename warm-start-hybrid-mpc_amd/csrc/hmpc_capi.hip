@@ -231,7 +231,13 @@ void hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
     for (int c = 0; c < 3; c++) {
         if (cfg[c].k.kc > 0) continue;                                   // a register kernel serves this wave count
         if (cfg[c].k.big && c != (only >= 0 ? only : 2)) continue;
-        shapes[count] = hmpc_jit_shape{cfg[c].k.big ? -1 : 0, -1, 0, 0, 0, 0, 1 << c, 0, 0, fields};
+        // Row state (slack, multiplier, two steps per row) in registers instead of the global slab where a lane holds at most 16
+        // rows (HMPC_JIT_SIZED_ROWS: another limit, 0: never): the list row map with Rows<Mpad / threads>.  configs[4], 12 rows
+        // per lane: HBM traffic per launch 65 -> 45 GB, 137.0 -> 133.6 ms (profiles/r04_c4_rows_ab.txt); 164 B of scratch per lane.
+        int rs = p.Mpad / (WAVE << c), rs_max = 16;
+        if (const char *e = getenv("HMPC_JIT_SIZED_ROWS")) rs_max = atoi(e);
+        if (rs > rs_max) rs = 0;
+        shapes[count] = hmpc_jit_shape{cfg[c].k.big ? -1 : 0, -1, 0, rs, 0, 0, 1 << c, 0, 0, fields};
         slot[count++] = c;
     }
     if (!count) return;

@@ -144,7 +144,7 @@ inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
 {
     char b[160];
     if (!s.sized.empty()) {
-        snprintf(b, sizeof b, "hmpc_s_%s_w%d_%016llx_%016llx", s.nx < 0 ? "stream" : "generic", s.nw, (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
+        snprintf(b, sizeof b, "hmpc_s_%s_w%d_r%d_%016llx_%016llx", s.nx < 0 ? "stream" : "generic", s.nw, s.kf, (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
         return b;
     }
     snprintf(b, sizeof b, "hmpc_k_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "", (unsigned long long)hsh);
@@ -167,8 +167,8 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
         std::ofstream out(src);
         if (!s.sized.empty())
             out << "// generated by hmpc_jit.h: the run-time-sized kernel with the sizes of one problem as constants\n#define HMPC_KERNEL_ONLY\n#define HMPC_SIZED(p) " << s.sized
-                << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<"
-                << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", -1, 0, 0, 0, 0, " << s.nw << ", true>;\n}\nextern \"C\" const char *hmpc_jit_sized(void) { return \""
+                << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<"
+                << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ", true>;\n}\nextern \"C\" const char *hmpc_jit_sized(void) { return \""
                 << s.sized << "\"; }\n";
         else
         out << "// generated by hmpc_jit.h: the register kernel of one problem shape\n#define HMPC_KERNEL_ONLY\n#define HMPC_JIT_KC " << s.kc

@@ -3451,8 +3451,13 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     const DevProb &p = p_arg;
 #endif
     constexpr int RS = KF + KB + KT;
-    typedef Dims<NX_, NU_, NUB_, NW, (RS > 0 && RS <= 8)> D;
+    typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0 && RS <= 8)> D;
+#ifdef HMPC_SIZED
+    // (a sized kernel may keep the row state of the list row map in registers: KF = Mpad / (64 NW) slots, KB = KT = 0)
+    static_assert(NX_ <= 0, "sized kernels are the run-time-sized forms");
+#else
     static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernels the lists");
+#endif
     typedef typename std::conditional<(NX_ > 0), RowMapS<D, KF, KB, KT>, RowMapL<D>>::type RM;
     const int lane = threadIdx.x; // thread of the workgroup; wave 0 (lane < 64) runs the recursions
     const int nx = D::nx(p), nu = D::nu(p), nz = D::nz(p), T = p.T, nub = D::nub(p), M = p.M, n = T * nz + nx, ne = D::ne(p);
