@@ -1,6 +1,6 @@
-"""The problems of the test suite and of bench.py whose kernels ``hmpc_create`` compiles at first use (csrc/hmpc_jit.h):
-register kernels for shapes without a built-in instantiation, the run-time-sized kernel with the problem's sizes where the
-static row map does not hold the problem.  ``prewarm()`` compiles them into the cache ahead of time, without a GPU
+"""The problems of the test suite and of bench.py: ``hmpc_create`` compiles the kernels of a problem with its sizes as
+constants at first use (csrc/hmpc_jit.h) -- register kernels where the static row map holds the problem, the run-time-sized
+kernel or its streaming form elsewhere.  ``prewarm()`` compiles them into the cache ahead of time, without a GPU
 (``jit_prebuild``) -- ``__graft_entry__.build()`` calls it, so that a GPU box (which has the compiler too) meets cache hits:
 
     python tests/jit_problems.py
@@ -18,6 +18,10 @@ SIZED = ((20, 6, 8, 0, 30),       # BASELINE configs[4]: beyond one CU's LDS, th
          (10, 4, 4, 5, 8))        # nx + nu = 18: beyond the static row map, fits LDS (1 / 2 / 4 waves per node)
 
 
+# (fixture, T, terminal set): the controllers of tests/ and bench.py (helpers.make_controller)
+CONTROLLERS = tuple((f, T, term) for f in ('cart_pole_with_walls', 'cart_pole_one_wall') for T in (10, 20, 40) for term in (True, False))
+
+
 def problem(nx, nuc, nub, seed, T):
     from warm_start_hmpc_amd.controller import HybridModelPredictiveController
     mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
@@ -26,11 +30,13 @@ def problem(nx, nuc, nub, seed, T):
 
 def prewarm(verbose=False):
     from warm_start_hmpc_amd.qp_backend import jit_prebuild
+    from helpers import make_controller
     paths = []
-    for spec in REGISTER_SHAPES + SIZED:
-        got = jit_prebuild(problem(*spec)[0])
+    for spec in CONTROLLERS + REGISTER_SHAPES + SIZED:
+        data = make_controller(spec[0], T=spec[1], terminal=spec[2], backend=_NoBackend()).problem_data() if isinstance(spec[0], str) else problem(*spec)[0]
+        got = jit_prebuild(data)
         if verbose:
-            print(spec, [os.path.basename(p) for p in got])
+            print(spec, [os.path.basename(p) for p in got], flush=True)
         paths += got
     return paths
 

@@ -122,7 +122,7 @@ def test_headline_kernel_keeps_its_register_budget(tmp_path):
     assert scratch and max(scratch) == 0, scratch
 
 
-def test_register_kernel_is_compiled_for_an_arbitrary_shape():
+def test_register_kernel_is_compiled_for_an_arbitrary_shape(monkeypatch):
     # The reference takes any MLDSystem (warm_start_hmpc/controller.py:58-117); the fast kernel here is a compile-time
     # instantiation.  For a shape without a built-in one hmpc_create compiles it from the same source into an on-disk
     # cache (csrc/hmpc_jit.h); hmpc_jit_build does the same without a GPU.  A random MLD with nx = 6, nu = 2 + 3 -- three
@@ -133,6 +133,7 @@ def test_register_kernel_is_compiled_for_an_arbitrary_shape():
     from helpers import random_mld, _NoBackend
     from warm_start_hmpc_amd.controller import HybridModelPredictiveController
     from warm_start_hmpc_amd.qp_backend import jit_shapes, jit_prebuild
+    monkeypatch.setenv('HMPC_JIT_SIZED', '0')      # (the per-shape kernels; the default -- per problem -- in the next test)
     mld, objective, x0 = random_mld(nx=6, nuc=2, nub=3, seed=3)
     ctrl = HybridModelPredictiveController(mld, 8, objective, None, backend=_NoBackend())
     shapes = jit_shapes(ctrl.problem_data())
@@ -156,7 +157,11 @@ def test_run_time_sized_kernel_is_compiled_with_the_sizes_of_a_problem():
     import time
     from jit_problems import problem, SIZED
     from warm_start_hmpc_amd.qp_backend import jit_prebuild
-    for spec, names in zip(SIZED, (['hmpc_s_stream_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'])):
+    from jit_problems import REGISTER_SHAPES
+    cases = list(zip(SIZED, (['hmpc_s_stream_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'])))
+    # ... and where the static row map holds the problem, the register kernel with the row slots its horizon needs
+    cases.append((REGISTER_SHAPES[0], ['hmpc_s_reg_6_5_3_4_1_1_w1_kc8_o2', 'hmpc_s_reg_6_5_3_2_1_1_w2_kc8', 'hmpc_s_reg_6_5_3_1_1_1_w4_kc8']))
+    for spec, names in cases:
         data = problem(*spec)[0]
         paths = jit_prebuild(data)
         assert [os.path.basename(p)[:len(n)] for p, n in zip(paths, names)] == names and len(paths) == len(names), paths

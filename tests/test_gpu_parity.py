@@ -374,7 +374,7 @@ def test_register_kernel_compiled_for_an_arbitrary_shape():
         mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
         ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
         hip, orc = HipBatchedQP(ctrl.problem_data()), OracleBatchedQP(ctrl.problem_data(), threads=8)
-        assert hip.kernel_info() == (3, 3, 3), hip.kernel_info()
+        assert hip.kernel_info() == (6, 6, 6), hip.kernel_info()   # (compiled with the problem's sizes; 3: per shape, HMPC_JIT_SIZED=0)
         Cj = np.array([mld.F[2 * nx + 2 * nuc + 4 * j] for j in range(nub)])
         leaf = np.full((1, T * nub), -1, np.int8)
         for t in range(T):

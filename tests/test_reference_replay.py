@@ -32,7 +32,10 @@ X0 = np.array([0., 0., 1., 0.])
 # cost the same to 4e-10 relative (test_the_one_deviation_from_the_published_covers_is_a_tie below).  The dive meets the
 # one that is worse in the tenth digit first, so the subtree of the other is opened as well: 3 more solves, 2 more
 # leaves, carried for three steps until the shift drops them.  Gurobi met them in the other order (or saw them equal).
-KNOWN_TIES = {('0003', 94): {11: 175, 12: 175, 13: 175}}
+# Which of the two is met first is decided by the last digits of the bounds: the oracle, the shipped kernel and the fleet driver
+# carry both extra leaves (175), the kernel compiled with the problem's sizes -- same algorithm, another instruction schedule --
+# one of them at the first of the three steps (174).  Pinned: between the published cover and the published cover + 2.
+KNOWN_TIES = {('0003', 94): {11: (173, 175), 12: (173, 175), 13: (173, 175)}}
 
 
 def _compare(st, tag, sims, steps, max_lost=1.0, warm_mean=True):
@@ -49,9 +52,10 @@ def _compare(st, tag, sims, steps, max_lost=1.0, warm_mean=True):
         assert len(lw) == n, (tag, i, len(lw), n)                        # the simulation ends where the published one does
         want = ref['nodes_len_ws_' + tag][i, :n].copy()
         tie = KNOWN_TIES.get((tag, i), {})
-        for t, v in tie.items():
+        for t, (lo, hi) in tie.items():
             if t < n:
-                want[t] = v
+                assert lo <= lw[t] <= hi, (tag, i, t, lw[t])
+                want[t] = lw[t]
         assert np.array_equal(lw, want), (tag, i)                        # cover sizes: exactly the published ones
         m = len(cs)                                                      # == n, or n + 1: the step that has no solution
         assert m == (n + 1 if n < min(steps, 50) else n), (tag, i, m, n)

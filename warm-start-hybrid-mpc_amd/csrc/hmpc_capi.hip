@@ -159,7 +159,9 @@ int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
 // Register kernels of this problem's shape for 1 / 2 / 4 waves per node, compiled or fetched from the cache (hmpc_jit.h).
 // Shapes with a built-in instantiation, shapes the static row map does not hold, and hosts without a compiler leave jit
 // empty: hmpc_pick_kernel then takes what it always took.
-void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu, std::vector<std::string> *built)
+// shapes_only: nothing is built -- jit gets placeholders (waves, kc, occ2) for hmpc_pick_kernel; the kernels that run are then
+// compiled WITH THE PROBLEM'S SIZES by hmpc_jit_prepare_sized.
+void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu, std::vector<std::string> *built, bool shapes_only)
 {
     if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return;
     if ((p.nx == 4 && p.nu == 7 && p.nub == 4) || (p.nx == 4 && p.nu == 4 && p.nub == 2)) return; // (built in)
@@ -177,6 +179,10 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
         slot[count++] = c;
     }
     if (!count) return;
+    if (shapes_only) {
+        for (int i = 0; i < count; i++) jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0, shapes[i].occ2};
+        return;
+    }
     std::vector<std::string> paths;
     std::string err;
     (void)hmpc_jit_build_all(shapes, count, paths, err);
@@ -184,7 +190,7 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
         if (paths[i].empty()) continue;
         if (built) {                                                     // (dry run: built, not loaded; the choice of kernels must still see it)
             built->push_back(paths[i]);
-            jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0};
+            jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0, shapes[i].occ2};
             continue;
         }
         void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
@@ -194,7 +200,7 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
         void *cold = nullptr, *warm = nullptr;
         get(&cold, &warm);
         libs.push_back(lib);
-        jit[slot[i]] = {(hmpc_kernel_t)cold, (hmpc_kernel_t)warm, shapes[i].nw, kc, 0};
+        jit[slot[i]] = {(hmpc_kernel_t)cold, (hmpc_kernel_t)warm, shapes[i].nw, kc, 0, shapes[i].occ2};
     }
     if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: register kernel for this shape not available (%s): the run-time-sized kernel serves it\n", err.c_str());
 }
@@ -216,37 +222,59 @@ std::string hmpc_sized_fields(const DevProb &p)
     return b;
 }
 
-// Sized kernels (hmpc_jit.h) for the wave counts of this problem that the run-time-sized kernel or its streaming form would
-// serve: compiled or fetched from the cache, they replace it in `cfg`.  The streaming form runs four waves per node
-// whatever the batch (hmpc_solve_batch_device), so only that one is built.  HMPC_JIT_SIZED=0: none.
-void hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<void *> &libs, int &count_out, std::vector<std::string> *built)
+static bool hmpc_sized_enabled()
 {
-    if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return; // (the run-time-sized kernels themselves are asked for)
-    if (const char *e = getenv("HMPC_JIT_SIZED")) { if (atoi(e) == 0) return; }
+    if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return false; // (the run-time-sized kernels themselves are asked for)
+    if (const char *e = getenv("HMPC_JIT")) { if (atoi(e) == 0) return false; }
+    if (const char *e = getenv("HMPC_JIT_SIZED")) { if (atoi(e) == 0) return false; }
+    return true;
+}
+
+// SIZED KERNELS (hmpc_jit.h): whatever kernel hmpc_pick_kernel chose for a wave count -- a register kernel of the problem's
+// shape (built in, or a placeholder of hmpc_jit_prepare), the run-time-sized kernel or its streaming form -- is compiled with
+// this problem's sizes as constants (or fetched from the cache) and replaces the choice in `cfg`.  Register kernels get
+// exactly the row slots the horizon needs.  The streaming form runs four waves per node whatever the batch
+// (hmpc_solve_batch_device), so only that one is built.  Returns false if a placeholder could not be replaced (the caller
+// then falls back to the kernels without sizes).
+bool hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<void *> &libs, int &count_out, std::vector<std::string> *built)
+{
     const std::string fields = hmpc_sized_fields(p);
     hmpc_jit_shape shapes[3];
     int slot[3], count = 0;
     int only = -1;
     if (const char *e = getenv("HMPC_WAVES")) { const int nw = atoi(e); only = nw == 1 ? 0 : nw == 2 ? 1 : nw == 4 ? 2 : -1; }
     for (int c = 0; c < 3; c++) {
-        if (cfg[c].k.kc > 0) continue;                                   // a register kernel serves this wave count
-        if (cfg[c].k.big && c != (only >= 0 ? only : 2)) continue;
+        const hmpc_kernel_choice &k = cfg[c].k;
+        if (k.kc > 0) {                                                 // register kernel: the static row map with the slots this horizon needs
+            int kf = 0, kb = 0, kt = 0;
+            if (!hmpc_static_slots(p, k.waves, kf, kb, kt)) continue;
+            if (kt < 1) kt = 1;
+            shapes[count] = hmpc_jit_shape{p.nx, p.nu, p.nub, kf, kb, kt, k.waves, k.kc, k.occ2, fields};
+            slot[count++] = c;
+            continue;
+        }
+        if (k.big && c != (only >= 0 ? only : 2)) continue;
         // Row state (slack, multiplier, two steps per row) in registers instead of the global slab where a lane holds at most 16
         // rows (HMPC_JIT_SIZED_ROWS: another limit, 0: never): the list row map with Rows<Mpad / threads>.  configs[4], 12 rows
         // per lane: HBM traffic per launch 65 -> 45 GB, 137.0 -> 133.6 ms (profiles/r04_c4_rows_ab.txt); 164 B of scratch per lane.
         int rs = p.Mpad / (WAVE << c), rs_max = 16;
         if (const char *e = getenv("HMPC_JIT_SIZED_ROWS")) rs_max = atoi(e);
         if (rs > rs_max) rs = 0;
-        shapes[count] = hmpc_jit_shape{cfg[c].k.big ? -1 : 0, -1, 0, rs, 0, 0, 1 << c, 0, 0, fields};
+        shapes[count] = hmpc_jit_shape{k.big ? -1 : 0, -1, 0, rs, 0, 0, 1 << c, 0, 0, fields};
         slot[count++] = c;
     }
-    if (!count) return;
     std::vector<std::string> paths;
     std::string err;
-    (void)hmpc_jit_build_all(shapes, count, paths, err);
+    if (count) (void)hmpc_jit_build_all(shapes, count, paths, err);
     for (int i = 0; i < count; i++) {
         if (paths[i].empty()) continue;
-        if (built) { built->push_back(paths[i]); continue; }           // (dry run: built, not loaded)
+        if (built) {                                                     // (dry run: built, not loaded)
+            bool seen = false;
+            for (const std::string &b : *built) seen |= b == paths[i];
+            if (!seen) built->push_back(paths[i]);
+            cfg[slot[i]].sized = 1;
+            continue;
+        }
         void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!lib) { err = std::string("dlopen: ") + dlerror(); continue; }
         auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
@@ -260,7 +288,10 @@ void hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
         cfg[slot[i]].sized = 1;
         count_out++;
     }
-    if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: sized kernel for this problem not available (%s): the run-time-sized kernel serves it\n", err.c_str());
+    if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: sized kernel for this problem not available (%s): the kernel without sizes serves it\n", err.c_str());
+    for (int c = 0; c < 3; c++)
+        if (!cfg[c].sized && cfg[c].k.fn == (hmpc_kernel_t)(uintptr_t)1) return false;
+    return true;
 }
 
 } // namespace
@@ -519,22 +550,28 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
     }
     // shapes without a built-in instantiation: the register kernel is compiled now (or found in the cache), hmpc_jit.h
     hmpc_kernel_choice jit[3] = {};
-    hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu, built);
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
-    for (int c = 0; c < 3; c++) {
-        hmpc_cfg &cf = h->cfg[c];
-        cf.k = hmpc_pick_kernel(p, 1 << c, jit);
-        cf.lds = hmpc_lds_bytes(p, cf.k.kc, cf.k.big);
-        if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
-            char msg[256];
-            snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max > 0 ? lds_max : (int)lds_cu);
-            hmpc_destroy(h);
-            return fail(HMPC_ETOOBIG, msg);
+    for (int pass = 0; pass < 2; pass++) {
+        // first the kernels compiled with this problem's sizes (hmpc_jit.h); without them (HMPC_JIT_SIZED=0, no compiler at run
+        // time) the shipped kernels and, for other shapes of the static row map, register kernels compiled per shape
+        const bool sized = pass == 0 && hmpc_sized_enabled();
+        if (pass == 0 && !sized) continue;
+        for (int c = 0; c < 3; c++) { jit[c] = hmpc_kernel_choice{}; h->cfg[c] = hmpc_cfg{}; }
+        hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu, built, sized);
+        for (int c = 0; c < 3; c++) {
+            hmpc_cfg &cf = h->cfg[c];
+            cf.k = hmpc_pick_kernel(p, 1 << c, jit);
+            cf.lds = hmpc_lds_bytes(p, cf.k.kc, cf.k.big);
+            if (cf.lds > lds_cu || (lds_max > 0 && cf.lds > (size_t)lds_max)) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "problem needs %zu bytes of LDS per node, more than one CU has (%d)", cf.lds, lds_max > 0 ? lds_max : (int)lds_cu);
+                hmpc_destroy(h);
+                return fail(HMPC_ETOOBIG, msg);
+            }
         }
+        if (!sized || hmpc_jit_prepare_sized(p, h->cfg, h->jit_libs, h->jit_kernels, built)) break;
     }
-    // wave counts left to the run-time-sized kernel: that kernel compiled with this problem's sizes (or found in the cache)
-    hmpc_jit_prepare_sized(p, h->cfg, h->jit_libs, h->jit_kernels, built);
     if (dry) { delete h; return HMPC_OK; }
     for (int c = 0; c < 3; c++) {
         hmpc_cfg &cf = h->cfg[c];
@@ -616,8 +653,8 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
 }
 
 // Which kind of kernel serves this problem, per waves per node (1, 2, 4): 0 run-time-sized, 1 its streaming form,
-// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create, 4 / 5 the run-time-sized kernel /
-// its streaming form compiled with this problem's sizes at hmpc_create.
+// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create, 4 / 5 / 6 the run-time-sized kernel /
+// its streaming form / the register kernel compiled with this problem's sizes at hmpc_create.
 extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
 {
     if (!h || !kind3) return fail(HMPC_EINVAL, "null argument");
@@ -630,7 +667,7 @@ extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
             if (get) get(&a, &b);
             jitted |= a == (void *)k.fn;
         }
-        kind3[c] = k.kc > 0 ? (jitted ? 3 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
+        kind3[c] = k.kc > 0 ? (h->cfg[c].sized ? 6 : jitted ? 3 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
     }
     return HMPC_OK;
 }

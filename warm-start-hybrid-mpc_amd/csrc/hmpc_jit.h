@@ -143,6 +143,11 @@ inline uint64_t fnv(const std::string &t)
 inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
 {
     char b[160];
+    if (!s.sized.empty() && s.nx > 0) {
+        snprintf(b, sizeof b, "hmpc_s_reg_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "",
+                 (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
+        return b;
+    }
     if (!s.sized.empty()) {
         snprintf(b, sizeof b, "hmpc_s_%s_w%d_r%d_%016llx_%016llx", s.nx < 0 ? "stream" : "generic", s.nw, s.kf, (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
         return b;
@@ -165,22 +170,21 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
     const std::string src = base + tag + ".hip", tmp = base + tag + ".tmp.so";
     {
         std::ofstream out(src);
-        if (!s.sized.empty())
-            out << "// generated by hmpc_jit.h: the run-time-sized kernel with the sizes of one problem as constants\n#define HMPC_KERNEL_ONLY\n#define HMPC_SIZED(p) " << s.sized
-                << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<"
-                << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw << ", true>;\n}\nextern \"C\" const char *hmpc_jit_sized(void) { return \""
-                << s.sized << "\"; }\n";
-        else
-        out << "// generated by hmpc_jit.h: the register kernel of one problem shape\n#define HMPC_KERNEL_ONLY\n#define HMPC_JIT_KC " << s.kc
-            << "\n#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << s.nx << ", " << s.nu << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", "
-            << s.kt << ", " << s.nw << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<" << s.nx << ", " << s.nu
-            << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", " << s.kt << ", " << s.nw << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << s.nx << ", " << s.nu << ", "
-            << s.nub << ", " << s.kf << ", " << s.kb << ", " << s.kt << ", " << s.nw << ", true>;\n}\n";
+        // (the kernel template is renamed in every generated unit: its host stubs must not share their names with the shipped
+        // library's -- a process that links the library directly has those in its global scope)
+        out << "// generated by hmpc_jit.h\n#define HMPC_KERNEL_ONLY\n#define hmpc_qp_kernel hmpc_qp_kernel_jit\n";
+        if (s.nx > 0) out << "#define HMPC_JIT_KC " << s.kc << "\n";
+        if (!s.sized.empty()) out << "#define HMPC_SIZED(p) " << s.sized << "\n";
+        std::stringstream args;
+        if (s.nx > 0) args << s.nx << ", " << s.nu << ", " << s.nub << ", " << s.kf << ", " << s.kb << ", " << s.kt << ", " << s.nw;
+        else args << s.nx << ", -1, 0, " << s.kf << ", 0, 0, " << s.nw;
+        out << "#include \"hmpc_device.h\"\n#include \"hmpc_kernel.hip\"\nHMPC_INSTANCE(" << args.str() << ")\nextern \"C\" void hmpc_jit_kernels(void **cold, void **warm)\n{\n    *cold = (void *)hmpc_qp_kernel<"
+            << args.str() << ", false>;\n    *warm = (void *)hmpc_qp_kernel<" << args.str() << ", true>;\n}\nextern \"C\" const char *hmpc_jit_sized(void) { return \"" << s.sized << "\"; }\n";
         if (!out) { err = "cannot write " + src; return -1; }
     }
     // the compiler runs as a CHILD process (posix_spawn, as Python's subprocess does): nothing of this process is replaced
     const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags() + (s.occ2 ? "'-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))' " : "") + " -I '" + include_dir() + "' -I '" +
-                            source_dir() + "' -shared -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
+                            source_dir() + "' -shared -Wl,-Bsymbolic -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
     pid_t pid = -1;
     const char *argv[] = {"sh", "-c", cmd.c_str(), nullptr};
     if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char *const *)argv, environ) != 0) { err = "cannot start the compiler"; return -1; }
@@ -222,9 +226,15 @@ inline bool hmpc_jit_build_all(const hmpc_jit_shape *shapes, int count, std::vec
     if (cache.empty()) { err = "no writable cache directory"; return false; }
     const uint64_t hsh = hmpc_jit::source_hash();
     std::vector<pid_t> pid(count, -1);
-    for (int i = 0; i < count; i++) pid[i] = hmpc_jit::start_build(shapes[i], cache, hsh, err);
+    std::vector<int> same(count, -1); // (two wave counts may be served by one kernel: built once)
+    for (int i = 0; i < count; i++) {
+        for (int j = 0; j < i && same[i] < 0; j++)
+            if (hmpc_jit::name_of(shapes[j], hsh) == hmpc_jit::name_of(shapes[i], hsh)) same[i] = j;
+        if (same[i] < 0) pid[i] = hmpc_jit::start_build(shapes[i], cache, hsh, err);
+    }
     bool all = true;
     for (int i = 0; i < count; i++) {
+        if (same[i] >= 0) { paths[i] = paths[same[i]]; all = all && !paths[i].empty(); continue; }
         if (pid[i] >= 0 && hmpc_jit::finish_build(pid[i], shapes[i], cache, hsh, err)) paths[i] = cache + "/" + hmpc_jit::name_of(shapes[i], hsh) + ".so";
         else all = false;
     }

@@ -3454,7 +3454,7 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0 && RS <= 8)> D;
 #ifdef HMPC_SIZED
     // (a sized kernel may keep the row state of the list row map in registers: KF = Mpad / (64 NW) slots, KB = KT = 0)
-    static_assert(NX_ <= 0, "sized kernels are the run-time-sized forms");
+    static_assert(NX_ <= 0 || RS > 0, "a sized register kernel keeps its row slots");
 #else
     static_assert((NX_ > 0) == (RS > 0), "compile-time shapes use the static row map, the generic kernels the lists");
 #endif
@@ -3791,6 +3791,7 @@ struct hmpc_kernel_choice {
     int waves;
     int kc;  // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
     int big; // generic kernel with lists and factor in global memory (Dims::kBig)
+    int occ2 = 0; // (a register kernel compiled at hmpc_create for two waves per SIMD, hmpc_jit.h)
 };
 // Waves per node, measured on MI355X (cart-pole N=20, ms per batch with 1 / 2 / 4 waves):
 //   8 nodes 1.81 / 1.50 / 1.41    77: 2.78 / 2.26 / 2.09    256: 2.88 / 2.47 / 2.30

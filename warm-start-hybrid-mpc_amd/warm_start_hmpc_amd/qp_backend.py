@@ -185,16 +185,18 @@ def jit_shapes(problem):
 
 
 def jit_prebuild(problem):
-    """Compiles (or finds in the cache) what ``hmpc_create`` would compile for ``problem`` -- without a GPU: the register
-    kernels of its shape (``hmpc_jit_build``, incl. the two-waves-per-SIMD build of the one-wave kernel, whichever of the
-    two ``hmpc_create`` picks), or -- where the static row map does not hold the problem -- the run-time-sized kernel with the
-    problem's sizes (``hmpc_jit_build_problem``).  Returns the paths of the shared objects."""
+    """Compiles (or finds in the cache) what ``hmpc_create`` would compile for ``problem`` -- without a GPU
+    (``hmpc_jit_build_problem``): the kernels of the problem with its sizes as constants -- register kernels where the static
+    row map holds the problem, the run-time-sized kernel or its streaming form elsewhere.  With ``HMPC_JIT_SIZED=0`` the
+    register kernels per SHAPE of round 4's first form (``hmpc_jit_build``, incl. the two-waves-per-SIMD build of the one-wave
+    kernel).  Returns the paths of the shared objects."""
     lib = load_library()
     lib.hmpc_jit_build.restype = ctypes.c_int
     lib.hmpc_jit_build.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_char_p, ctypes.c_int32]
     lib.hmpc_jit_build_problem.restype = ctypes.c_int
     lib.hmpc_jit_build_problem.argtypes = [ctypes.POINTER(_Problem), ctypes.POINTER(_Options), ctypes.c_char_p, ctypes.c_int32]
-    if not jit_shapes(problem):
+    if not jit_shapes(problem) or os.environ.get('HMPC_JIT_SIZED', '1') != '0':
+        # (the default: every kernel compiled with the problem's sizes; HMPC_JIT_SIZED=0: register kernels per shape, below)
         p, keep = _problem_struct(problem)
         buf = ctypes.create_string_buffer(8192)
         if lib.hmpc_jit_build_problem(ctypes.byref(p), None, buf, 8192) != 0:
@@ -359,8 +361,8 @@ class HipBatchedQP(object):
 
     def kernel_info(self):
         """Kind of kernel that serves this problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming form,
-        2 built-in register kernel, 3 register kernel compiled for this shape at creation, 4 / 5 the run-time-sized kernel /
-        its streaming form compiled with this problem's sizes at creation (``hmpc_kernel_info``)."""
+        2 built-in register kernel, 3 register kernel compiled for this shape at creation, 4 / 5 / 6 the run-time-sized kernel /
+        its streaming form / the register kernel compiled with this problem's sizes at creation (``hmpc_kernel_info``)."""
         k = (ctypes.c_int32 * 3)()
         self.lib.hmpc_kernel_info.restype = ctypes.c_int
         self.lib.hmpc_kernel_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
