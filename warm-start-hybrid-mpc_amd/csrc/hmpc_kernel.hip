@@ -3451,7 +3451,14 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     const DevProb &p = p_arg;
 #endif
     constexpr int RS = KF + KB + KT;
+#if defined(HMPC_SIZED) && !defined(HMPC_DPP_FEW)
+    // A kernel compiled with the problem's sizes has the registers for the DPP broadcasts whatever its number of row slots
+    // (one-wave kernel of the headline: 215 AGPRs, no scratch -> 92 B of scratch, +4.6 %; N = 40, two waves: +8.5 %; a shape
+    // compiled at hmpc_create, nx = 6, nu = 2 + 3: +11 %; profiles/r04_dpp_ab.txt)
+    typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0)> D;
+#else
     typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0 && RS <= 8)> D;
+#endif
 #ifdef HMPC_SIZED
     // (a sized kernel may keep the row state of the list row map in registers: KF = Mpad / (64 NW) slots, KB = KT = 0)
     static_assert(NX_ <= 0 || RS > 0, "a sized register kernel keeps its row slots");
