@@ -1,4 +1,6 @@
-// hmpc_jit.h -- register kernels for ANY admissible MLD shape, compiled when a problem is created (host code only).
+// hmpc_jit.h -- kernels compiled when a problem is created (host code only): the kernel of each wave count WITH THE PROBLEM'S
+// SIZES as constants (hmpc_jit_shape::sized; hmpc_jit_prepare_sized in hmpc_capi.hip), and -- the first form of
+// round 4, now the second choice -- register kernels per SHAPE for any admissible MLD system:
 //
 // The reference accepts any MLDSystem at one speed (warm_start_hmpc/controller.py:58-117).  Here the fast kernel --
 // hmpc_qp_kernel<NX, NU, NUB, KF, KB, KT, NW> with the static row map: rows in registers, recursions in registers of wave
