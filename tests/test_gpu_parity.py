@@ -455,6 +455,32 @@ def test_sized_kernels_of_a_problem_beyond_the_static_row_map():
         np.testing.assert_allclose(c['obj'][fin], a['obj'][fin], rtol=1e-9, atol=1e-12)
 
 
+def test_compiled_kernels_are_checked_at_their_first_launch(monkeypatch, capfd):
+    # A kernel compiled at hmpc_create is code nobody has run before: the first launch through it solves the first nodes of its
+    # batch with the shipped kernel of the same wave count as well and compares (hmpc_capi.hip: hmpc_check_compiled).  Agreement
+    # keeps it; a disagreement (forced here by the test hook) drops it for the handle, loudly, and the shipped kernel serves --
+    # same records either way.
+    x0 = np.array([0., 0., .5, 0.])
+    fix = random_prefix_frontier(10, 4, 24, p_one=0.1)
+    fix[0, :] = -1
+    good = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    a = good.qp.solve_batch(x0, fix)
+    assert good.qp.kernel_info() == (6, 6, 6)
+    assert 'disagrees' not in capfd.readouterr().err
+    monkeypatch.setenv('HMPC_JIT_SELFCHECK_FAIL', '1')
+    bad = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    assert bad.qp.kernel_info() == (6, 6, 6)
+    b = bad.qp.solve_batch(x0, fix)                                        # (24 nodes: four waves per node)
+    monkeypatch.delenv('HMPC_JIT_SELFCHECK_FAIL')
+    assert bad.qp.kernel_info() == (6, 6, 2), bad.qp.kernel_info()         # dropped where it was launched, and only there
+    assert 'disagrees with the shipped kernel' in capfd.readouterr().err
+    assert np.array_equal(a['status'], b['status'])
+    fin = a['status'] == 0
+    np.testing.assert_allclose(a['obj'][fin], b['obj'][fin], rtol=1e-9, atol=1e-12)
+    c = bad.qp.solve_batch(x0, fix)                                        # the shipped kernel from then on: bit-equal to itself
+    assert np.array_equal(b['obj'], c['obj'])
+
+
 def test_two_launch_form_of_the_lazy_terminal_set(monkeypatch):
     # Opt-in (HMPC_SPLIT=1): large cold batches leave the nodes that need the terminal-set rows to a second launch (four
     # waves per node, each from its own first record: hmpc_capi.hip, DevWarm).  Same statuses and the same vertices as the

@@ -20,6 +20,7 @@
 #include "hmpc_jit.h"      // register kernels for shapes without a built-in instantiation, compiled at hmpc_create
 #include "hmpc_shift.hip"
 
+#define HMPC_CHECK_NODES 6 // nodes of the first-use check of a kernel compiled at hmpc_create (hmpc_check_compiled)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
 {
@@ -38,6 +39,13 @@ struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve
     size_t lds = 0;
     int max_grid = 0;
     int sized = 0; // k is the run-time-sized kernel compiled with this problem's sizes (hmpc_jit_prepare_sized)
+    // FIRST-USE CHECK of a kernel compiled at hmpc_create: `ref` is the shipped kernel that would serve this wave count without
+    // the run-time compiler; the first launch through this configuration solves its first few nodes with both and compares
+    // statuses and objectives (hmpc_check_compiled).  A kernel that disagrees is dropped for the handle.
+    hmpc_kernel_choice ref{};
+    size_t ref_lds = 0;
+    int ref_grid = 0;
+    int checked = 0; // 0 not yet, 1 agreed, -1 disagreed (ref serves)
 };
 
 struct hmpc_handle {
@@ -61,6 +69,8 @@ struct hmpc_handle {
     void *h_stage = nullptr; // its pinned host mirror
     int staged = 0;
     bool staged_warm = false; // the blocks have room for one handed-down parent record per node
+    void *chk = nullptr;          // device block of the first-use check: 2 x HMPC_CHECK_NODES x (obj, dual_obj, status, iters)
+    int jit_rejected = 0;         //   compiled kernels dropped by it
     std::vector<void *> jit_libs; // shared objects of kernels compiled for this problem's shape (hmpc_jit.h); never unloaded
     int jit_kernels = 0;          //   how many of the three wave counts run on such a kernel (hmpc_kernel_info)
 };
@@ -588,9 +598,34 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
     }
     h->lds = h->cfg[0].lds;
     for (int c = 0; c < 3; c++) h->jit_kernels += jit[c].fn != nullptr && h->cfg[c].k.fn == jit[c].fn;
+    // kernels compiled at hmpc_create are checked against the shipped kernel of the same wave count at their first launch
+    bool ref_big = false;
+    {
+        const char *e = getenv("HMPC_JIT_SELFCHECK");
+        const bool on = !(e && atoi(e) == 0);
+        for (int c = 0; c < 3 && on; c++) {
+            hmpc_cfg &cf = h->cfg[c];
+            const hmpc_kernel_choice ref = hmpc_pick_kernel(p, 1 << c, nullptr);
+            if (ref.fn == cf.k.fn) continue;                            // (a shipped kernel serves: nothing was compiled)
+            const size_t lds = hmpc_lds_bytes(p, ref.kc, ref.big);
+            if (lds > lds_cu || (lds_max > 0 && lds > (size_t)lds_max)) continue;
+            if (hipFuncSetAttribute((const void *)ref.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            cf.ref = ref;
+            cf.ref_lds = lds;
+            int per_cu = (int)(lds_cu / lds);
+            if (per_cu > 8) per_cu = 8;
+            cf.ref_grid = (cus > 0 ? cus : 256) * per_cu;
+            if (cf.ref_grid > h->max_grid) h->max_grid = cf.ref_grid;   // (the workspaces below must hold its launches too)
+            ref_big = ref_big || ref.big;
+        }
+        if (hipMalloc(&h->chk, 2 * HMPC_CHECK_NODES * 2 * sizeof(double) + 2 * HMPC_CHECK_NODES * 2 * sizeof(int32_t)) != hipSuccess) {
+            hmpc_destroy(h);
+            return fail(HMPC_EDEVICE, "cannot allocate the check block");
+        }
+    }
     p.fac_ws = nullptr;
     p.fac_stride = 0;
-    if (h->cfg[0].k.big || h->cfg[1].k.big || h->cfg[2].k.big) {
+    if (h->cfg[0].k.big || h->cfg[1].k.big || h->cfg[2].k.big || ref_big) {
         p.fac_stride = p.T * (p.nx * p.nu + p.nu * (p.nu - 1) / 2) + (p.T + 1) * (p.nx * (p.nx + 1) / 2);
         if (hipMalloc((void **)&p.fac_ws, (size_t)h->max_grid * p.fac_stride * sizeof(double)) != hipSuccess) {
             hmpc_destroy(h);
@@ -645,6 +680,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->order) (void)hipFree(h->order);
     if (h->pend) (void)hipFree(h->pend);
     if (h->d_shift) (void)hipFree(h->d_shift);
+    if (h->chk) (void)hipFree(h->chk);
     if (h->trace) (void)hipFree(h->trace);
     if (h->d_x0) (void)hipFree(h->d_x0);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -804,6 +840,58 @@ extern "C" int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *ld
     return HMPC_OK;
 }
 
+// FIRST-USE CHECK of a kernel compiled at hmpc_create (hmpc_cfg::ref).  The run-time compiler produces code nobody has run
+// before for a problem nobody has seen -- and this kernel lives at the edge of the register file, where a diagnostic variant
+// of the configs[4] kernel was once seen to come out wrong from the compiler's VGPR -> AGPR spilling (correct with
+// -amdgpu-spill-vgpr-to-agpr=0 and at -O1; profiles/r04_check_build.txt).  So the first launch through a configuration solves
+// the first few nodes of ITS batch with the compiled kernel and with the shipped kernel of the same wave count, and compares
+// statuses and objectives (1e-6 relative: the two are the same algorithm).  Agreement: the compiled kernel serves from then
+// on.  Disagreement: it is dropped for this handle, loudly.  One stream synchronisation, once per configuration.
+static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0, int x0_stride, const int8_t *d_fix, int B, hipStream_t stream)
+{
+    cf.checked = 1;
+    if (!cf.ref.fn || !h->chk || h->trace) return HMPC_OK;
+    const int nb = B < HMPC_CHECK_NODES ? B : HMPC_CHECK_NODES;
+    double *obj = (double *)h->chk, *dobj = obj + 2 * HMPC_CHECK_NODES;
+    int32_t *st = (int32_t *)(dobj + 2 * HMPC_CHECK_NODES), *it = st + 2 * HMPC_CHECK_NODES;
+    const DevWarm w{nullptr, nullptr, nullptr, nullptr, 0};
+    for (int which = 0; which < 2; which++) {
+        const hmpc_kernel_choice &k = which ? cf.k : cf.ref;
+        const size_t lds = which ? cf.lds : cf.ref_lds;
+        const DevOut o{obj + which * HMPC_CHECK_NODES, dobj + which * HMPC_CHECK_NODES, st + which * HMPC_CHECK_NODES, it + which * HMPC_CHECK_NODES, nullptr, nullptr};
+        HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k.fn, dim3(nb), dim3(64 * k.waves), lds, stream, h->dp, d_x0, x0_stride, d_fix, nb, o, h->rows_ws, (double *)nullptr,
+                           (const int32_t *)nullptr, w);
+        HIPCHK(hipGetLastError());
+    }
+    double hobj[2 * HMPC_CHECK_NODES];
+    int32_t hst[2 * HMPC_CHECK_NODES];
+    HIPCHK(hipMemcpyAsync(hobj, obj, sizeof hobj, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hst, st, sizeof hst, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    bool same = true;
+    for (int b = 0; b < nb; b++) {
+        const int sa = hst[b], sb = hst[HMPC_CHECK_NODES + b];
+        same = same && sa == sb;
+        if (sa == HMPC_OPTIMAL && sb == HMPC_OPTIMAL) {
+            const double a = hobj[b], c = hobj[HMPC_CHECK_NODES + b];
+            same = same && std::fabs(a - c) <= 1e-6 * (1.0 + std::fabs(a));
+        }
+    }
+    if (getenv("HMPC_JIT_SELFCHECK_FAIL")) same = false; // (test hook: the path a disagreement takes)
+    if (!same) {
+        fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) disagrees with the shipped kernel on the first nodes of its first batch: "
+                        "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n", cf.k.waves);
+        cf.k = cf.ref;
+        cf.lds = cf.ref_lds;
+        cf.max_grid = cf.ref_grid;
+        cf.sized = 0;
+        cf.checked = -1;
+        h->jit_rejected++;
+    }
+    return HMPC_OK;
+}
+
 extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix,
                                        int32_t B, const hmpc_warm *d_warm, const hmpc_result *d_out, void *stream)
 {
@@ -821,7 +909,12 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     int nw = hmpc_waves_for(B, h->cfg[0].max_grid);
     // the streaming form holds one node per CU whatever the number of waves: always spread it over all four SIMDs
     if (h->cfg[2].k.big && !getenv("HMPC_WAVES")) nw = 4;
-    const hmpc_cfg &cf = h->cfg[nw == 1 ? 0 : nw == 2 ? 1 : 2];
+    hmpc_cfg &cfm = h->cfg[nw == 1 ? 0 : nw == 2 ? 1 : 2];
+    if (!cfm.checked) {
+        const int rc = hmpc_check_compiled(h, cfm, d_x0, x0_stride, d_fix, B, (hipStream_t)stream);
+        if (rc != HMPC_OK) return rc;
+    }
+    const hmpc_cfg &cf = cfm;
     const hmpc_kernel_choice &k = cf.k;
     const int grid = B < cf.max_grid ? B : cf.max_grid;
     h->last_grid = grid;

@@ -109,7 +109,19 @@ inline std::string cache_dir()
 
 // extra compiler flags of the kernels compiled per shape (part of the cache key), e.g. an occupancy attribute:
 //   HMPC_JIT_FLAGS='-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))'
-inline std::string extra_flags() { const char *e = getenv("HMPC_JIT_FLAGS"); return e ? e : ""; }
+// A diagnostic build of the library (make check / make stamps) compiles its kernels the same way.
+inline std::string extra_flags()
+{
+    const char *e = getenv("HMPC_JIT_FLAGS");
+    std::string f = e ? e : "";
+#ifdef HMPC_CHECK
+    f += " -DHMPC_CHECK";
+#endif
+#ifdef HMPC_STAMPS
+    f += " -DHMPC_STAMPS";
+#endif
+    return f;
+}
 
 inline std::string quoted_flags() // (each blank-separated flag in single quotes: attributes carry parentheses)
 {

@@ -3598,14 +3598,26 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         }
 #ifdef HMPC_CHECK
         {
+#ifdef HMPC_POISON_FINITE // (bisecting: is it the VALUE that is read, or only the code around the stores that differs)
+            const double poison = 1.0;
+#else
             const double poison = __longlong_as_double(0x7ff8dead0000beefLL);
+#endif
             // everything per node between the iterate and the staged constants (S.w .. S.mv); the node's inputs and the
             // staged problem data are not touched
             for (ldsd *q = S.w + lane; q < S.red; q += D::kNT) *q = poison;
             const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
 #pragma unroll
             for (int k = 0; k < nslot; k++) {
-                if constexpr (RS > 0) { R.s_[k] = poison; R.zd_[k] = poison; R.dz_[k] = poison; R.prod_[k] = poison; }
+#ifndef HMPC_POISON_MASK
+#define HMPC_POISON_MASK 15 // (which of the four row arrays are poisoned: bisecting a read of something never written)
+#endif
+                if constexpr (RS > 0) {
+                    if (HMPC_POISON_MASK & 1) R.s_[k] = poison;
+                    if (HMPC_POISON_MASK & 2) R.zd_[k] = poison;
+                    if (HMPC_POISON_MASK & 4) R.dz_[k] = poison;
+                    if (HMPC_POISON_MASK & 8) R.prod_[k] = poison;
+                }
             }
             __syncthreads();
         }
