@@ -174,3 +174,24 @@ def test_run_time_sized_kernel_is_compiled_with_the_sizes_of_a_problem():
             assert ('p.nx=%d;p.nu=%d;p.nub=%d;' % (nx, nuc + nub, nub)) in fields and ('p.T=%d;' % T) in fields
         tic = time.perf_counter()
         assert jit_prebuild(data) == paths and time.perf_counter() - tic < 2.0                    # (cache hits)
+
+
+def test_two_processes_compile_the_same_problem_into_an_empty_cache(tmp_path):
+    # one process per GPU (bench.py --gpus N, torch.distributed): on a cold cache every rank compiles the same kernels at the
+    # same time -- each into a file of its own, moved into place atomically; both end with the same, loadable shared objects
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import conftest; from helpers import make_controller, _NoBackend; "
+            "from warm_start_hmpc_amd.qp_backend import jit_prebuild; "
+            "print('\\n'.join(jit_prebuild(make_controller('cart_pole_one_wall', T=10, backend=_NoBackend()).problem_data())))"
+            % os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HMPC_JIT_CACHE=str(tmp_path))
+    procs = [subprocess.Popen([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    paths = [o[0].split() for o in outs]
+    assert paths[0] == paths[1] and len(paths[0]) == 2 and all(q.startswith(str(tmp_path)) for q in paths[0])   # (2 and 4 waves per node)
+    for q in paths[0]:
+        assert hasattr(ctypes.CDLL(q), 'hmpc_jit_kernels')
+    left = sorted(f for f in os.listdir(tmp_path) if not f.endswith('.so'))
+    assert left == [], left                                                                    # no temporary files stay behind

@@ -481,6 +481,31 @@ def test_compiled_kernels_are_checked_at_their_first_launch(monkeypatch, capfd):
     assert np.array_equal(b['obj'], c['obj'])
 
 
+def test_without_a_compiler_at_run_time_the_shipped_kernels_serve(monkeypatch, tmp_path):
+    # hmpc_create compiles the kernels of a problem (csrc/hmpc_jit.h); a host without the compiler -- or without the sources, or
+    # with an empty cache it cannot fill -- gets the shipped kernels: built-in register kernels for the cart-pole shapes, the
+    # run-time-sized kernel for every other system.  Same records.
+    from jit_problems import problem, REGISTER_SHAPES
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    x0 = np.array([0., 0., .5, 0.])
+    fix = random_prefix_frontier(10, 4, 48, p_one=0.1)
+    fix[0, :] = -1
+    a = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    assert a.qp.kernel_info() == (6, 6, 6)
+    monkeypatch.setenv('HMPC_HIPCC', '/nonexistent/hipcc')
+    monkeypatch.setenv('HMPC_JIT_CACHE', str(tmp_path))
+    b = make_controller('cart_pole_with_walls', T=10, backend='hip')
+    assert b.qp.kernel_info() == (2, 2, 2), b.qp.kernel_info()
+    ra, rb = a.qp.solve_batch(x0, fix), b.qp.solve_batch(x0, fix)
+    assert np.array_equal(ra['status'], rb['status'])
+    fin = ra['status'] == 0
+    np.testing.assert_allclose(ra['obj'][fin], rb['obj'][fin], rtol=1e-9, atol=1e-12)
+    data, mld, objective, xr = problem(*REGISTER_SHAPES[0])
+    c = HipBatchedQP(data)
+    assert c.kernel_info() == (0, 0, 0), c.kernel_info()
+    assert os.listdir(tmp_path) == []
+
+
 def test_two_launch_form_of_the_lazy_terminal_set(monkeypatch):
     # Opt-in (HMPC_SPLIT=1): large cold batches leave the nodes that need the terminal-set rows to a second launch (four
     # waves per node, each from its own first record: hmpc_capi.hip, DevWarm).  Same statuses and the same vertices as the
