@@ -28,8 +28,10 @@ def problem(nx, nuc, nub, seed, T):
     return HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend()).problem_data(), mld, objective, x0
 
 
-def prewarm(verbose=False):
-    from warm_start_hmpc_amd.qp_backend import jit_prebuild
+def prewarm(verbose=False, prune=False):
+    """prune: entries of the IN-TREE cache that none of these problems uses are deleted afterwards -- what an edit of the kernel
+    sources leaves behind (the key holds a hash of the sources); the directory travels to the GPU boxes with the tree."""
+    from warm_start_hmpc_amd.qp_backend import jit_prebuild, LIBRARY_PATH
     from helpers import make_controller
     paths = []
     for spec in CONTROLLERS + REGISTER_SHAPES + SIZED:
@@ -38,8 +40,14 @@ def prewarm(verbose=False):
         if verbose:
             print(spec, [os.path.basename(p) for p in got], flush=True)
         paths += got
+    cache = os.path.join(os.path.dirname(LIBRARY_PATH), 'jit_cache')
+    if prune and os.path.isdir(cache) and paths and all(os.path.dirname(q) == cache for q in paths):
+        keep = set(os.path.basename(q) for q in paths)
+        for f in os.listdir(cache):
+            if f not in keep:
+                os.remove(os.path.join(cache, f))
     return paths
 
 
 if __name__ == '__main__':
-    prewarm(verbose=True)
+    prewarm(verbose=True, prune='--prune' in sys.argv)
