@@ -114,6 +114,15 @@ inline std::string extra_flags()
 {
     const char *e = getenv("HMPC_JIT_FLAGS");
     std::string f = e ? e : "";
+    // Instruction scheduling for ILP: these kernels run ONE wave per SIMD, nothing hides a latency but the schedule itself,
+    // and the compiler's default strategy schedules for occupancy first.  Measured on the kernels compiled with the problem's
+    // sizes (profiles/r04_sched_ab.txt): headline 510 -> 524 k QP/s, N = 40 118 -> 130 k, configs[4] 30.7 -> 32.1 k
+    // (iterative-minreg: 468 / 114 / 27.4 k; max-ilp: 500 k on the headline).  HMPC_JIT_SCHED=<strategy> | default.
+    if (f.find("amdgpu-sched-strategy") == std::string::npos) {
+        const char *sc = getenv("HMPC_JIT_SCHED");
+        const std::string strat = sc ? sc : "iterative-ilp";
+        if (strat != "default") f += " -mllvm -amdgpu-sched-strategy=" + strat;
+    }
 #ifdef HMPC_CHECK
     f += " -DHMPC_CHECK";
 #endif
