@@ -114,15 +114,6 @@ inline std::string extra_flags()
 {
     const char *e = getenv("HMPC_JIT_FLAGS");
     std::string f = e ? e : "";
-    // Instruction scheduling for ILP: these kernels run ONE wave per SIMD, nothing hides a latency but the schedule itself,
-    // and the compiler's default strategy schedules for occupancy first.  Measured on the kernels compiled with the problem's
-    // sizes (profiles/r04_sched_ab.txt): headline 510 -> 524 k QP/s, N = 40 118 -> 130 k, configs[4] 30.7 -> 32.1 k
-    // (iterative-minreg: 468 / 114 / 27.4 k; max-ilp: 500 k on the headline).  HMPC_JIT_SCHED=<strategy> | default.
-    if (f.find("amdgpu-sched-strategy") == std::string::npos) {
-        const char *sc = getenv("HMPC_JIT_SCHED");
-        const std::string strat = sc ? sc : "iterative-ilp";
-        if (strat != "default") f += " -mllvm -amdgpu-sched-strategy=" + strat;
-    }
 #ifdef HMPC_CHECK
     f += " -DHMPC_CHECK";
 #endif
@@ -132,9 +123,24 @@ inline std::string extra_flags()
     return f;
 }
 
-inline std::string quoted_flags() // (each blank-separated flag in single quotes: attributes carry parentheses)
+// Instruction scheduling for ILP (-amdgpu-sched-strategy=iterative-ilp): these kernels run ONE wave per SIMD, nothing hides a
+// latency but the schedule itself, and the compiler's default strategy schedules for occupancy first.  Measured on the kernels
+// compiled with the problem's sizes (profiles/r04_sched_ab.txt): N = 40, two waves per node 118 -> 130 k QP/s, configs[4]
+// 30.7 -> 32.1 k.  NOT for the register kernels with one wave per node: with up to 15 row slots per lane the longer live
+// ranges spill -- headline 510 -> 524 k QP/s but 84 -> 236 B of scratch (HBM traffic 1.37x -> 5.6x algorithmic), the kernel
+// with the hand-down and the two-waves-per-SIMD builds LOSE (fleet of 1024 loops 42 -> 27 k steps/s, a shape compiled for two
+// waves per SIMD 520 -> 451 k QP/s): those keep the default.  HMPC_JIT_SCHED=<strategy> | default: for every kernel.
+inline std::string sched_flags(const hmpc_jit_shape &s)
 {
-    std::stringstream in(extra_flags());
+    if (extra_flags().find("amdgpu-sched-strategy") != std::string::npos) return "";
+    std::string strat = (s.nx > 0 && s.nw == 1) ? "default" : "iterative-ilp";
+    if (const char *sc = getenv("HMPC_JIT_SCHED")) strat = sc;
+    return strat == "default" ? std::string() : "-mllvm -amdgpu-sched-strategy=" + strat;
+}
+
+inline std::string quoted_flags(const hmpc_jit_shape &s) // (each blank-separated flag in single quotes: attributes carry parentheses)
+{
+    std::stringstream in(extra_flags() + " " + sched_flags(s));
     std::string tok, out;
     while (in >> tok) out += "'" + tok + "' ";
     return out;
@@ -163,9 +169,10 @@ inline uint64_t fnv(const std::string &t)
     return hsh;
 }
 
-inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh)
+inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh0)
 {
     char b[160];
+    const uint64_t hsh = hsh0 ^ (sched_flags(s).empty() ? 0ull : fnv(sched_flags(s))); // (the schedule is part of the key)
     if (!s.sized.empty() && s.nx > 0) {
         snprintf(b, sizeof b, "hmpc_s_reg_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "",
                  (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
@@ -206,7 +213,7 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
         if (!out) { err = "cannot write " + src; return -1; }
     }
     // the compiler runs as a CHILD process (posix_spawn, as Python's subprocess does): nothing of this process is replaced
-    const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags() + (s.occ2 ? "'-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))' " : "") + " -I '" + include_dir() + "' -I '" +
+    const std::string cmd = compiler() + " --offload-arch=gfx950 -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags(s) + (s.occ2 ? "'-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))' " : "") + " -I '" + include_dir() + "' -I '" +
                             source_dir() + "' -shared -Wl,-Bsymbolic -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
     pid_t pid = -1;
     const char *argv[] = {"sh", "-c", cmd.c_str(), nullptr};
