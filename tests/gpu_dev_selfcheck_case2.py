@@ -1,0 +1,33 @@
+"""Diagnostic: variants of the kernels of a problem whose compiled kernels came out wrong (see gpu_dev_selfcheck_case.py)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import conftest  # noqa
+import numpy as np
+from helpers import random_mld, _NoBackend
+from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+from oracle.oracle_qp import OracleBatchedQP
+os.environ['HMPC_JIT_SELFCHECK'] = '0'
+for spec in ((9, 3, 4, 6, 23), (9, 3, 4, 10, 23), (8, 4, 4, 6, 23), (10, 2, 4, 6, 23), (9, 3, 3, 6, 23)):
+    nx, nuc, nub, T, seed = spec
+    mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
+    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    orc = OracleBatchedQP(ctrl.problem_data(), threads=16)
+    fix = np.full((4, T * nub), -1, np.int8)
+    fix[1, :nub] = 0
+    fix[2, :2 * nub] = 0
+    fix[3, 0] = 1
+    b = orc.solve_batch(x0, fix)
+    for label, env in (('sized', {}), ('sized, readlane broadcasts', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_FEW'}), ('per shape', {'HMPC_JIT_SIZED': '0'})):
+        os.environ.update(env)
+        hip = HipBatchedQP(ctrl.problem_data())
+        for k in env:
+            del os.environ[k]
+        out = []
+        for waves in ('1', '2', '4'):
+            os.environ['HMPC_WAVES'] = waves
+            a = hip.solve_batch(x0, fix)
+            del os.environ['HMPC_WAVES']
+            out.append('w%s %s' % (waves, 'ok' if np.array_equal(a['status'], b['status']) else 'WRONG %s' % a['status']))
+        print(spec, 'nz', nx + nuc + nub, label, hip.kernel_info(), '; '.join(out), 'oracle', b['status'], flush=True)

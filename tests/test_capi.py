@@ -158,7 +158,7 @@ def test_run_time_sized_kernel_is_compiled_with_the_sizes_of_a_problem():
     from jit_problems import problem, SIZED
     from warm_start_hmpc_amd.qp_backend import jit_prebuild
     from jit_problems import REGISTER_SHAPES
-    cases = list(zip(SIZED, (['hmpc_s_stream_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'])))
+    cases = list(zip(SIZED, (['hmpc_s_stream_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'], ['hmpc_s_generic_w1', 'hmpc_s_generic_w2', 'hmpc_s_generic_w4'])))
     # ... and where the static row map holds the problem, the register kernel with the row slots its horizon needs
     cases.append((REGISTER_SHAPES[0], ['hmpc_s_reg_6_5_3_4_1_1_w1_kc8_o2', 'hmpc_s_reg_6_5_3_2_1_1_w2_kc8', 'hmpc_s_reg_6_5_3_1_1_1_w4_kc8']))
     for spec, names in cases:

@@ -409,16 +409,18 @@ def test_register_kernel_compiled_for_an_arbitrary_shape():
         np.testing.assert_allclose(g['obj'][fin], a['obj'][fin], rtol=1e-8, atol=1e-11)
 
 
-def test_sized_kernels_of_a_problem_beyond_the_static_row_map():
-    # nx + nu = 18: no register kernel (the static row map ends at 16), the problem fits one CU's LDS -- the run-time-sized
+@pytest.mark.parametrize('which', [1, 2])
+def test_sized_kernels_of_a_problem_beyond_the_static_row_map(which):
+    # nx + nu = 18 / 16: no register kernel (the static row map ends at 15 -- a problem with nx + nu = 16 is the one whose
+    # register kernels the first-use check of round 4 found wrong), the problem fits one CU's LDS -- the run-time-sized
     # kernel compiled with the problem's sizes serves 1 / 2 / 4 waves per node (csrc/hmpc_jit.h, round 4).  Same records as
     # the oracle at the one tolerance, and as the shipped run-time-sized kernel (HMPC_JIT_SIZED=0).
     from jit_problems import problem, SIZED
     from warm_start_hmpc_amd.controller import HybridModelPredictiveController
     from warm_start_hmpc_amd.qp_backend import HipBatchedQP
     from oracle.oracle_qp import OracleBatchedQP
-    nx, nuc, nub, seed, T = SIZED[1]
-    data, mld, objective, x0 = problem(*SIZED[1])
+    nx, nuc, nub, seed, T = SIZED[which]
+    data, mld, objective, x0 = problem(*SIZED[which])
     ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
     hip, orc = HipBatchedQP(data), OracleBatchedQP(data, threads=8)
     assert hip.kernel_info() == (4, 4, 4), hip.kernel_info()

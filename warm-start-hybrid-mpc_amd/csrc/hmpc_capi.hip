@@ -175,7 +175,7 @@ void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vecto
 {
     if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return;
     if ((p.nx == 4 && p.nu == 7 && p.nub == 4) || (p.nx == 4 && p.nu == 4 && p.nub == 2)) return; // (built in)
-    if (!p.static_rows || p.nz > 16 || p.nub < 1) return;
+    if (!p.static_rows || p.nz > 15 || p.nub < 1) return; // (nz = 16: see factor_reg)
     const int kc = std::max(2, (p.kcol + 1) / 2 * 2);
     if (kc > HMPC_KC_STRIDE || hmpc_lds_bytes(p, kc, 0) > lds_cu) return;
     hmpc_jit_shape shapes[3];
@@ -314,7 +314,7 @@ extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
 extern "C" int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len)
 {
     g_err.clear();
-    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 16 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || ((nw & 7) != 1 && (nw & 7) != 2 && (nw & 7) != 4) || (nw & ~15) || kc < 2 ||
+    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 15 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || ((nw & 7) != 1 && (nw & 7) != 2 && (nw & 7) != 4) || (nw & ~15) || kc < 2 ||
         kc > HMPC_KC_STRIDE || (kc & 1))
         return fail(HMPC_EINVAL, "jit: not a shape of the static row map");
     hmpc_jit_shape s{nx, nu, nub, kf, kb, kt, nw & 7, kc, (nw & 8) ? 1 : 0}; // (nw + 8: the two-waves-per-SIMD build of the one-wave kernel)

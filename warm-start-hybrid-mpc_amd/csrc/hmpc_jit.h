@@ -5,7 +5,7 @@
 // The reference accepts any MLDSystem at one speed (warm_start_hmpc/controller.py:58-117).  Here the fast kernel --
 // hmpc_qp_kernel<NX, NU, NUB, KF, KB, KT, NW> with the static row map: rows in registers, recursions in registers of wave
 // 0 -- is a compile-time instantiation; the library ships the two cart-pole shapes of the reference.  For every other
-// shape that meets the static row map's requirements (nx + nu <= 16; every [F G] row with at most two input coefficients;
+// shape that meets the static row map's requirements (nx + nu <= 15; every [F G] row with at most two input coefficients;
 // columns of at most 16 entries; at most 64 Gram entries with terms; at least one binary -- DevProb::static_rows,
 // hmpc_pick_kernel) hmpc_create compiles the instantiation FROM THE SAME SOURCE with the toolchain the library was built
 // with: one small translation unit per number of waves per node,

@@ -159,12 +159,12 @@ def _problem_struct(problem):
 def jit_shapes(problem):
     """The register-kernel shapes ``hmpc_create`` compiles for ``problem`` (csrc/hmpc_jit.h): a list of
     (nx, nu, nub, kf, kb, kt, nw, kc) for 1 / 2 / 4 waves per node, empty where the static row map does not hold the
-    problem (nx + nu > 16, an [F G] row with more than two input coefficients, no binary, a built-in shape).  Mirrors the
+    problem (nx + nu > 15, an [F G] row with more than two input coefficients, no binary, a built-in shape).  Mirrors the
     host code of ``hmpc_create`` / ``hmpc_static_slots``; used to warm the cache ahead of time (``jit_prebuild``)."""
     nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
     F, G = np.atleast_2d(problem['F']), np.atleast_2d(problem['G'])
     nc, nT = F.shape[0], np.atleast_2d(problem['F_Tm1']).shape[0] - F.shape[0]
-    if (nx, nu, nub) in ((4, 7, 4), (4, 4, 2)) or nx + nu > 16 or nub < 1 or nc + 2 * nub > 255:
+    if (nx, nu, nub) in ((4, 7, 4), (4, 4, 2)) or nx + nu > 15 or nub < 1 or nc + 2 * nub > 255:
         return []
     if np.any(np.count_nonzero(G, axis=1) > 2):
         return []
