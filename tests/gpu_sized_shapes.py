@@ -23,13 +23,22 @@ bad = 0
 SHAPES = ((5, 2, 2, 9, 21), (7, 3, 3, 14, 22), (9, 3, 4, 6, 23), (4, 1, 5, 16, 24),          # register kernels
           (12, 4, 4, 10, 25), (13, 3, 5, 7, 26), (16, 4, 0, 8, 8), (10, 6, 6, 9, 27),         # run-time-sized kernel with sizes
           (22, 2, 3, 24, 5), (17, 9, 7, 20, 2), (30, 4, 6, 16, 4))                            # streaming form
+# DBG_EDGE=1: small and lopsided shapes instead -- one state, no continuous input, one binary, many binaries, the shortest
+# horizons, the last admissible nx + nu of the register kernels (15), horizons that outgrow the row slots
+if os.environ.get('DBG_EDGE'):
+    SHAPES = ((1, 1, 1, 4, 31), (2, 0, 2, 5, 32), (3, 1, 1, 2, 33), (6, 0, 3, 8, 34), (11, 2, 2, 5, 35), (5, 5, 5, 3, 36), (14, 0, 1, 6, 37),
+              (3, 3, 6, 12, 38), (2, 1, 8, 4, 39), (8, 2, 2, 30, 40), (6, 2, 3, 40, 41), (4, 2, 1, 25, 42))
 for nx, nuc, nub, T, seed in SHAPES:
-    mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
-    ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    try:
+        mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
+        ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
+    except Exception as e:
+        print('skip nx=%d nu=%d+%d T=%d (generator): %s' % (nx, nuc, nub, T, repr(e)[:80]))
+        continue
     tic = time.perf_counter()
     try:
         hip = HipBatchedQP(ctrl.problem_data())
-    except RuntimeError as e:
+    except (RuntimeError, ValueError) as e:
         print('skip nx=%d nu=%d+%d T=%d: %s' % (nx, nuc, nub, T, str(e)[:80]))
         continue
     tcreate = time.perf_counter() - tic
