@@ -1,5 +1,7 @@
 """Diagnostic: a problem whose compiled kernels the first-use check dropped (random MLD nx=9, nu=3+4, T=6, seed 23): the compiled
-kernels WITHOUT the check against the shipped kernel and the oracle, node by node."""
+kernels WITHOUT the check against the shipped kernel and the oracle, node by node.  (Reproduces on the tree BEFORE the static row
+map was cut back to nx + nu <= 15 -- commit "Register kernels end at nx + nu = 15"; since then the problem runs the run-time-sized
+kernel with sizes and everything here agrees.  Output of the time: profiles/r04_nz16_register_kernels.txt.)"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

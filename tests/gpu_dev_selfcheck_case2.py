@@ -1,4 +1,5 @@
-"""Diagnostic: variants of the kernels of a problem whose compiled kernels came out wrong (see gpu_dev_selfcheck_case.py)."""
+"""Diagnostic: variants of the kernels of a problem whose compiled kernels came out wrong (see gpu_dev_selfcheck_case.py; like it,
+it reproduces only before the static row map was cut back to nx + nu <= 15: profiles/r04_nz16_register_kernels.txt)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
