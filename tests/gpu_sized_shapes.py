@@ -84,8 +84,22 @@ for nx, nuc, nub, T, seed in SHAPES:
         dev = np.abs(a['primal'][both][:, :xs] - b['primal'][both][:, :xs]).max() if both.any() else 0.
         nan = int(np.isnan(a['primal'][a['status'] == 0]).sum() + np.isnan(a['dual']).sum())
         ok = same and dobj < 2e-6 and dship < 2e-6 and dev < 1e-5 and nan == 0 and np.all(a['status'] <= 1)
+        # the hand-down instantiation of the same kernels (hmpc_warm; the first-use check runs the cold kernel only): every
+        # optimal, polished node is handed ITS OWN record -- its active set verifies without an interior-point iteration --,
+        # every other node the record of its neighbour in the batch (mostly the wrong set: dropped, cold solve)
+        idx = np.where((a['status'] == 0) & (a['polished'] > 0), np.arange(count), np.where(a['status'][(np.arange(count) + 1) % count] == 0, (np.arange(count) + 1) % count, -1)).astype(np.int32)
+        os.environ['HMPC_WAVES'] = waves
+        try:
+            aw = hip.solve_batch(x0, fix, warm=(a['primal'], a['dual'], idx))
+            cw = plain.solve_batch(x0, fix, warm=(c['primal'], c['dual'], idx))
+        finally:
+            del os.environ['HMPC_WAVES']
+        own = (a['status'] == 0) & (a['polished'] > 0)
+        okw = np.array_equal(aw['status'], a['status']) and np.array_equal(cw['status'], a['status']) and (aw['iters'][own] == 0).mean() > 0.9 and \
+            (not opt.any() or np.max(np.abs(aw['obj'][opt] - a['obj'][opt]) / (1 + np.abs(a['obj'][opt]))) < 2e-6)
+        ok = ok and okw
         good = good and ok
-        line.append('w%s: obj %.0e / shipped %.0e, x %.0e%s' % (waves, dobj, dship, dev, '' if ok else ' FAIL'))
+        line.append('w%s: obj %.0e / shipped %.0e, x %.0e, handed down %d of %d%s' % (waves, dobj, dship, dev, int((aw['iters'][own] == 0).sum()), int(own.sum()), '' if ok else ' FAIL'))
     bad += not good
     print('ok  ' if good else 'FAIL', 'nx=%d nu=%d+%d T=%d: kinds %s (create %.0f s), optimal %d (polished on both sides %d), infeasible %d; %s'
           % (nx, nuc, nub, T, hip.kernel_info(), tcreate, int(opt.sum()), int(both.sum()), int((a['status'] == 1).sum()), '; '.join(line)), flush=True)
