@@ -10,17 +10,23 @@ from warm_start_hmpc_amd.controller import HybridModelPredictiveController
 from warm_start_hmpc_amd.qp_backend import HipBatchedQP
 from oracle.oracle_qp import OracleBatchedQP
 os.environ['HMPC_JIT_SELFCHECK'] = '0'
-for spec in ((9, 3, 4, 6, 23), (9, 3, 4, 10, 23), (8, 4, 4, 6, 23), (10, 2, 4, 6, 23), (9, 3, 3, 6, 23)):
+SPECS = ((9, 3, 4, 6, 23), (9, 3, 4, 10, 23), (8, 4, 4, 6, 23), (10, 2, 4, 6, 23), (9, 3, 3, 6, 23))
+if os.environ.get('DBG_SHAPES'):   # "nx,nuc,nub,T,seed;..."
+    SPECS = tuple(tuple(int(v) for v in q.split(',')) for q in os.environ['DBG_SHAPES'].split(';'))
+for spec in SPECS:
     nx, nuc, nub, T, seed = spec
     mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
     ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
     orc = OracleBatchedQP(ctrl.problem_data(), threads=16)
-    fix = np.full((4, T * nub), -1, np.int8)
+    fix = np.full((6, T * nub), -1, np.int8)
     fix[1, :nub] = 0
     fix[2, :2 * nub] = 0
     fix[3, 0] = 1
+    fix[4, :3] = 0
+    fix[5, :T * nub // 2] = 0
     b = orc.solve_batch(x0, fix)
-    for label, env in (('sized', {}), ('sized, readlane broadcasts', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_FEW'}), ('per shape', {'HMPC_JIT_SIZED': '0'})):
+    for label, env in (('sized', {}), ('sized, readlane broadcasts', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_FEW'}), ('sized, default schedule', {'HMPC_JIT_SCHED': 'default'}),
+                       ('sized, -O1', {'HMPC_JIT_FLAGS': '-O1'}), ('per shape', {'HMPC_JIT_SIZED': '0'})):
         os.environ.update(env)
         hip = HipBatchedQP(ctrl.problem_data())
         for k in env:

@@ -28,6 +28,8 @@ SHAPES = ((5, 2, 2, 9, 21), (7, 3, 3, 14, 22), (9, 3, 4, 6, 23), (4, 1, 5, 16, 2
 if os.environ.get('DBG_EDGE'):
     SHAPES = ((1, 1, 1, 4, 31), (2, 0, 2, 5, 32), (3, 1, 1, 2, 33), (6, 0, 3, 8, 34), (11, 2, 2, 5, 35), (5, 5, 5, 3, 36), (14, 0, 1, 6, 37),
               (3, 3, 6, 12, 38), (2, 1, 8, 4, 39), (8, 2, 2, 30, 40), (6, 2, 3, 40, 41), (4, 2, 1, 25, 42))
+if os.environ.get('DBG_SHAPES'):   # "nx,nuc,nub,T,seed;..."
+    SHAPES = tuple(tuple(int(v) for v in q.split(',')) for q in os.environ['DBG_SHAPES'].split(';'))
 for nx, nuc, nub, T, seed in SHAPES:
     try:
         mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)

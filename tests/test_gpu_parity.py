@@ -483,6 +483,39 @@ def test_compiled_kernels_are_checked_at_their_first_launch(monkeypatch, capfd):
     assert np.array_equal(b['obj'], c['obj'])
 
 
+def test_a_compiled_kernel_that_leaves_nodes_undecided_gets_a_second_opinion(monkeypatch, capfd):
+    # Random MLD nx = 8, nu = 5 + 2, N = 12: the four-wave register kernel the compiler of this image produces for it (sizes as
+    # constants, ILP schedule) is WRONG -- most nodes end NUMERICAL; right with the default schedule, at -O1, per shape, and on
+    # the bounds-checked build (profiles/r04_miscompiled_variants.txt).  The first-use check drops it.  With that check skipped
+    # (test hook) the second net catches it: a batch in which a compiled kernel leaves nodes MAXITER / NUMERICAL is solved again
+    # by the shipped kernel (hmpc_solve_batch), which decides them -- the caller gets right records, the compiled kernel is
+    # dropped.  Written so that it also holds on a toolchain that compiles the kernel right: then nothing is dropped.
+    from jit_problems import problem
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    data, mld, objective, x0 = problem(8, 5, 2, 55, 12)
+    T, nub = 12, 2
+    fix = np.full((24, T * nub), -1, np.int8)
+    for k in range(1, 24):
+        fix[k, :k] = 0
+    orc = OracleBatchedQP(data, threads=8)
+    b = orc.solve_batch(x0, fix)
+    monkeypatch.setenv('HMPC_JIT_SELFCHECK_SKIP_FIRST', '1')
+    hip = HipBatchedQP(data)
+    a = hip.solve_batch(x0, fix)                                          # (24 nodes: four waves per node)
+    monkeypatch.delenv('HMPC_JIT_SELFCHECK_SKIP_FIRST')
+    err = capfd.readouterr().err
+    assert np.array_equal(a['status'], b['status']) and np.all(a['status'] <= 1)
+    fin = a['status'] == 0
+    np.testing.assert_allclose(a['obj'][fin], b['obj'][fin], rtol=1e-6, atol=1e-9)
+    dropped = 'left' in err and 'undecided' in err
+    assert hip.kernel_info()[2] == (0 if dropped else 6), (hip.kernel_info(), err[-300:])
+    # the regular path: the first-use check decides
+    hip2 = HipBatchedQP(data)
+    a2 = hip2.solve_batch(x0, fix)
+    assert np.array_equal(a2['status'], b['status'])
+
+
 def test_without_a_compiler_at_run_time_the_shipped_kernels_serve(monkeypatch, tmp_path):
     # hmpc_create compiles the kernels of a problem (csrc/hmpc_jit.h); a host without the compiler -- or without the sources, or
     # with an empty cache it cannot fill -- gets the shipped kernels: built-in register kernels for the cart-pole shapes, the

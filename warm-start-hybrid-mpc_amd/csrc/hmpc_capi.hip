@@ -46,6 +46,7 @@ struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve
     size_t ref_lds = 0;
     int ref_grid = 0;
     int checked = 0; // 0 not yet, 1 agreed, -1 disagreed (ref serves)
+    int second_opinions = 0; // batches with MAXITER / NUMERICAL nodes that the shipped kernel solved again and ended the same way (hmpc_solve_batch)
 };
 
 struct hmpc_handle {
@@ -69,6 +70,8 @@ struct hmpc_handle {
     void *h_stage = nullptr; // its pinned host mirror
     int staged = 0;
     bool staged_warm = false; // the blocks have room for one handed-down parent record per node
+    int last_cfg = -1;            // configuration (0, 1, 2: 1 / 2 / 4 waves per node) of the last launch
+    bool use_ref = false;         // the next launch runs the shipped kernel of its configuration (second opinion, hmpc_solve_batch)
     void *chk = nullptr;          // device block of the first-use check: 2 x HMPC_CHECK_NODES x (obj, dual_obj, status, iters)
     int jit_rejected = 0;         //   compiled kernels dropped by it
     std::vector<void *> jit_libs; // shared objects of kernels compiled for this problem's shape (hmpc_jit.h); never unloaded
@@ -851,6 +854,7 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
 {
     cf.checked = 1;
     if (!cf.ref.fn || !h->chk || h->trace) return HMPC_OK;
+    if (getenv("HMPC_JIT_SELFCHECK_SKIP_FIRST")) return HMPC_OK; // (test hook: leaves a wrong kernel to the second opinion of hmpc_solve_batch)
     const int nb = B < HMPC_CHECK_NODES ? B : HMPC_CHECK_NODES;
     double *obj = (double *)h->chk, *dobj = obj + 2 * HMPC_CHECK_NODES;
     int32_t *st = (int32_t *)(dobj + 2 * HMPC_CHECK_NODES), *it = st + 2 * HMPC_CHECK_NODES;
@@ -910,11 +914,14 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     // the streaming form holds one node per CU whatever the number of waves: always spread it over all four SIMDs
     if (h->cfg[2].k.big && !getenv("HMPC_WAVES")) nw = 4;
     hmpc_cfg &cfm = h->cfg[nw == 1 ? 0 : nw == 2 ? 1 : 2];
+    h->last_cfg = nw == 1 ? 0 : nw == 2 ? 1 : 2;
     if (!cfm.checked) {
         const int rc = hmpc_check_compiled(h, cfm, d_x0, x0_stride, d_fix, B, (hipStream_t)stream);
         if (rc != HMPC_OK) return rc;
     }
-    const hmpc_cfg &cf = cfm;
+    hmpc_cfg shipped = cfm; // (second opinion: the shipped kernel of this configuration, hmpc_solve_batch)
+    if (h->use_ref && cfm.ref.fn) { shipped.k = cfm.ref; shipped.lds = cfm.ref_lds; shipped.max_grid = cfm.ref_grid; }
+    const hmpc_cfg &cf = (h->use_ref && cfm.ref.fn) ? shipped : cfm;
     const hmpc_kernel_choice &k = cf.k;
     const int grid = B < cf.max_grid ? B : cf.max_grid;
     h->last_grid = grid;
@@ -1092,6 +1099,42 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
         }
     }
 #endif
+    // SECOND OPINION on a kernel compiled at hmpc_create (variants of this kernel have come out wrong from the
+    // compiler, always loudly -- nodes ending NUMERICAL): a batch in which such a kernel leaves nodes MAXITER / NUMERICAL is
+    // solved again by the shipped kernel of the same wave count.  If that one decides more of them, the compiled kernel is
+    // dropped for the handle; either way the caller gets the shipped kernel's records for this batch.  After three batches
+    // on which both agree the compiled kernel is trusted with its hard nodes.  (Host-pointer entry only: the device-pointer
+    // entry does not see its statuses.)
+    if (!h->use_ref && out->status && h->last_cfg >= 0) {
+        hmpc_cfg &cc = h->cfg[h->last_cfg];
+        if (cc.ref.fn && cc.checked == 1 && cc.second_opinions < 3 && cc.k.fn != cc.ref.fn) {
+            const int32_t *st = (const int32_t *)(hs + L.status);
+            int hard = 0;
+            for (int b = 0; b < B; b++) hard += st[b] >= HMPC_MAXITER;
+            if (hard) {
+                h->use_ref = true;
+                const int rc2 = hmpc_solve_batch(h, x0, x0_stride, fix, B, warm, out);
+                h->use_ref = false;
+                if (rc2 != HMPC_OK) return rc2;
+                int hard_ref = 0;
+                for (int b = 0; b < B; b++) hard_ref += out->status[b] >= HMPC_MAXITER;
+                if (hard_ref < hard) {
+                    fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) left %d nodes of a batch undecided of which the shipped kernel decides %d: "
+                                    "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n",
+                            cc.k.waves, hard, hard - hard_ref);
+                    cc.k = cc.ref;
+                    cc.lds = cc.ref_lds;
+                    cc.max_grid = cc.ref_grid;
+                    cc.sized = 0;
+                    cc.checked = -1;
+                    h->jit_rejected++;
+                } else {
+                    cc.second_opinions++;
+                }
+                return HMPC_OK;
+            }
+        }
+    }
     if (out->obj) std::memcpy(out->obj, hs + L.obj, (size_t)B * sizeof(double));
     if (out->dual_obj) std::memcpy(out->dual_obj, hs + L.dobj, (size_t)B * sizeof(double));
     if (out->status) std::memcpy(out->status, hs + L.status, (size_t)B * sizeof(int32_t));
