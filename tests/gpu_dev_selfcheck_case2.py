@@ -27,8 +27,7 @@ for spec in SPECS:
     b = orc.solve_batch(x0, fix)
     for label, env in (('sized', {}), ('sized, readlane broadcasts', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_FEW'}), ('sized, default schedule', {'HMPC_JIT_SCHED': 'default'}),
                        ('sized, -O1', {'HMPC_JIT_FLAGS': '-O1'}), ('per shape', {'HMPC_JIT_SIZED': '0'}),
-                       ('sized, no VGPR -> AGPR spilling', {'HMPC_JIT_FLAGS': '-mllvm -amdgpu-spill-vgpr-to-agpr=0'}),
-                       ('sized, s_nop before every DPP broadcast', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_NOP'}))[(int(os.environ.get('DBG_FROM', 0))):]:
+                       ('sized, no VGPR -> AGPR spilling', {'HMPC_JIT_FLAGS': '-mllvm -amdgpu-spill-vgpr-to-agpr=0'}))[(int(os.environ.get('DBG_FROM', 0))):]:
         os.environ.update(env)
         hip = HipBatchedQP(ctrl.problem_data())
         for k in env:
