@@ -41,6 +41,12 @@ def prewarm(verbose=False, prune=False):
         if verbose:
             print(spec, [os.path.basename(p) for p in got], flush=True)
         paths += got
+    # the kernels compiled per SHAPE (HMPC_JIT_SIZED=0) of the one problem whose compilation test_capi.py walks through
+    os.environ['HMPC_JIT_SIZED'] = '0'
+    try:
+        paths += jit_prebuild(problem(*REGISTER_SHAPES[0])[0])
+    finally:
+        del os.environ['HMPC_JIT_SIZED']
     cache = os.path.join(os.path.dirname(LIBRARY_PATH), 'jit_cache')
     if prune and os.path.isdir(cache) and paths and all(os.path.dirname(q) == cache for q in paths):
         keep = set(os.path.basename(q) for q in paths)
