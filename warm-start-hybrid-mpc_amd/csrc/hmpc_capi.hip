@@ -20,7 +20,7 @@
 #include "hmpc_jit.h"      // register kernels for shapes without a built-in instantiation, compiled at hmpc_create
 #include "hmpc_shift.hip"
 
-#define HMPC_CHECK_NODES 6 // nodes of the first-use check of a kernel compiled at hmpc_create (hmpc_check_compiled)
+#define HMPC_CHECK_NODES 6 // (even) nodes of the first-use check of a kernel compiled at hmpc_create (hmpc_check_compiled)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
 {
@@ -621,7 +621,9 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
             if (cf.ref_grid > h->max_grid) h->max_grid = cf.ref_grid;   // (the workspaces below must hold its launches too)
             ref_big = ref_big || ref.big;
         }
-        if (hipMalloc(&h->chk, 2 * HMPC_CHECK_NODES * 2 * sizeof(double) + 2 * HMPC_CHECK_NODES * 2 * sizeof(int32_t)) != hipSuccess) {
+        // ((obj, dual_obj) x 3 runs, (status, iters) x 3 runs, the hand-down index, the records of the compiled kernel's cold run)
+        if (hipMalloc(&h->chk, 3 * HMPC_CHECK_NODES * 2 * sizeof(double) + 3 * HMPC_CHECK_NODES * 2 * sizeof(int32_t) + HMPC_CHECK_NODES * sizeof(int32_t) +
+                                   (size_t)HMPC_CHECK_NODES * (p.n_primal + p.n_dual) * sizeof(double)) != hipSuccess) {
             hmpc_destroy(h);
             return fail(HMPC_EDEVICE, "cannot allocate the check block");
         }
@@ -856,30 +858,54 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
     if (!cf.ref.fn || !h->chk || h->trace) return HMPC_OK;
     if (getenv("HMPC_JIT_SELFCHECK_SKIP_FIRST")) return HMPC_OK; // (test hook: leaves a wrong kernel to the second opinion of hmpc_solve_batch)
     const int nb = B < HMPC_CHECK_NODES ? B : HMPC_CHECK_NODES;
-    double *obj = (double *)h->chk, *dobj = obj + 2 * HMPC_CHECK_NODES;
-    int32_t *st = (int32_t *)(dobj + 2 * HMPC_CHECK_NODES), *it = st + 2 * HMPC_CHECK_NODES;
+    constexpr int N = HMPC_CHECK_NODES;
+    double *obj = (double *)h->chk, *dobj = obj + 3 * N;
+    int32_t *st = (int32_t *)(dobj + 3 * N), *it = st + 3 * N, *idx = it + 3 * N;
+    double *prim = (double *)(idx + N + (N & 1)), *dual = prim + (size_t)N * h->dp.n_primal; // (N even: the records stay 8-byte aligned)
     const DevWarm w{nullptr, nullptr, nullptr, nullptr, 0};
+    // runs 0 / 1: the shipped and the compiled kernel, cold (the compiled one keeps its records for run 2)
     for (int which = 0; which < 2; which++) {
         const hmpc_kernel_choice &k = which ? cf.k : cf.ref;
         const size_t lds = which ? cf.lds : cf.ref_lds;
-        const DevOut o{obj + which * HMPC_CHECK_NODES, dobj + which * HMPC_CHECK_NODES, st + which * HMPC_CHECK_NODES, it + which * HMPC_CHECK_NODES, nullptr, nullptr};
+        const DevOut o{obj + which * N, dobj + which * N, st + which * N, it + which * N, which ? prim : nullptr, which ? dual : nullptr};
         HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));
         hipLaunchKernelGGL(k.fn, dim3(nb), dim3(64 * k.waves), lds, stream, h->dp, d_x0, x0_stride, d_fix, nb, o, h->rows_ws, (double *)nullptr,
                            (const int32_t *)nullptr, w);
         HIPCHK(hipGetLastError());
     }
-    double hobj[2 * HMPC_CHECK_NODES];
-    int32_t hst[2 * HMPC_CHECK_NODES];
-    HIPCHK(hipMemcpyAsync(hobj, obj, sizeof hobj, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(hst, st, sizeof hst, hipMemcpyDeviceToHost, stream));
+    double hobj[3 * N];
+    int32_t hst[3 * N];
+    HIPCHK(hipMemcpyAsync(hobj, obj, 2 * N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hst, st, 2 * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     bool same = true;
     for (int b = 0; b < nb; b++) {
-        const int sa = hst[b], sb = hst[HMPC_CHECK_NODES + b];
+        const int sa = hst[b], sb = hst[N + b];
         same = same && sa == sb;
         if (sa == HMPC_OPTIMAL && sb == HMPC_OPTIMAL) {
-            const double a = hobj[b], c = hobj[HMPC_CHECK_NODES + b];
+            const double a = hobj[b], c = hobj[N + b];
             same = same && std::fabs(a - c) <= 1e-6 * (1.0 + std::fabs(a));
+        }
+    }
+    // run 2: the HAND-DOWN instantiation of the compiled kernel (its own binary), every optimal node handed its own record:
+    // same statuses, same objectives, and a polished node's active set verifies without an interior-point iteration
+    if (same && cf.k.fn_warm) {
+        int32_t hidx[N];
+        for (int b = 0; b < N; b++) hidx[b] = (b < nb && hst[N + b] == HMPC_OPTIMAL) ? b : -1;
+        HIPCHK(hipMemcpyAsync(idx, hidx, sizeof hidx, hipMemcpyHostToDevice, stream));
+        const DevWarm ww{prim, dual, idx, nullptr, 0};
+        const DevOut o{obj + 2 * N, dobj + 2 * N, st + 2 * N, it + 2 * N, nullptr, nullptr};
+        HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(cf.k.fn_warm, dim3(nb), dim3(64 * cf.k.waves), cf.lds, stream, h->dp, d_x0, x0_stride, d_fix, nb, o, h->rows_ws, (double *)nullptr,
+                           (const int32_t *)nullptr, ww);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(hobj + 2 * N, obj + 2 * N, N * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(hst + 2 * N, st + 2 * N, N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int b = 0; b < nb; b++) {
+            same = same && hst[2 * N + b] == hst[N + b];
+            if (hst[N + b] == HMPC_OPTIMAL && hst[2 * N + b] == HMPC_OPTIMAL)
+                same = same && std::fabs(hobj[2 * N + b] - hobj[N + b]) <= 1e-6 * (1.0 + std::fabs(hobj[N + b]));
         }
     }
     if (getenv("HMPC_JIT_SELFCHECK_FAIL")) same = false; // (test hook: the path a disagreement takes)
