@@ -126,16 +126,21 @@ inline std::string extra_flags()
 // Instruction scheduling for ILP (-amdgpu-sched-strategy=iterative-ilp): these kernels run ONE wave per SIMD, nothing hides a
 // latency but the schedule itself, and the compiler's default strategy schedules for occupancy first.  Measured on the kernels
 // compiled with the problem's sizes (profiles/r04_sched_ab.txt): N = 40, two waves per node 118 -> 130 k QP/s, configs[4]
-// 30.7 -> 32.1 k.  NOT for the register kernels with one wave per node: with up to 15 row slots per lane the longer live
-// ranges spill -- headline 510 -> 524 k QP/s but 84 -> 236 B of scratch (HBM traffic 1.37x -> 5.6x algorithmic), the kernel
-// with the hand-down and the two-waves-per-SIMD builds LOSE (fleet of 1024 loops 42 -> 27 k steps/s, a shape compiled for two
-// waves per SIMD 520 -> 451 k QP/s): those keep the default.  HMPC_JIT_SCHED=<strategy> | default: for every kernel.
+// 30.7 -> 32.1 k.  The register kernels with ONE wave per node (up to 15 row slots per lane) take it together with the
+// v_readlane broadcasts (-DHMPC_DPP_FEW: DPP only up to 8 slots, the rule of the shipped kernels): with the DPP broadcasts the
+// longer live ranges spill (headline 512 -> 524 k QP/s at 84 -> 236 B of scratch, the hand-down instantiation LOSES), with
+// v_readlane the same kernel has NO scratch and runs 563 k QP/s (profiles/r04_sched_ab.txt).  Kernels built for two waves
+// per SIMD (256 registers) keep the default schedule (ILP: 520 -> 451 k QP/s).  HMPC_JIT_SCHED=<strategy> | default: for every
+// kernel; a strategy in HMPC_JIT_FLAGS likewise.
 inline std::string sched_flags(const hmpc_jit_shape &s)
 {
-    if (extra_flags().find("amdgpu-sched-strategy") != std::string::npos) return "";
-    std::string strat = (s.nx > 0 && s.nw == 1) ? "default" : "iterative-ilp";
+    const bool one_wave_register = s.nx > 0 && s.nw == 1 && !s.occ2;
+    std::string f = one_wave_register ? "-DHMPC_DPP_FEW" : "";
+    if (extra_flags().find("amdgpu-sched-strategy") != std::string::npos) return f;
+    std::string strat = s.occ2 ? "default" : "iterative-ilp";
     if (const char *sc = getenv("HMPC_JIT_SCHED")) strat = sc;
-    return strat == "default" ? std::string() : "-mllvm -amdgpu-sched-strategy=" + strat;
+    if (strat != "default") f += std::string(f.empty() ? "" : " ") + "-mllvm -amdgpu-sched-strategy=" + strat;
+    return f;
 }
 
 inline std::string quoted_flags(const hmpc_jit_shape &s) // (each blank-separated flag in single quotes: attributes carry parentheses)
