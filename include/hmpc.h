@@ -298,7 +298,7 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
  * Problems the static row map does not hold (or too large for one CU's LDS) run the run-time-sized kernel / its streaming form
  * COMPILED WITH THE PROBLEM'S SIZES as constants, by the same mechanism (HMPC_JIT_SIZED=0: the shipped kernel): the same
  * code paths, 1.4x on BASELINE configs[4].  The same compilation is applied to the register kernels (exact row slots of the
- * horizon, no register spill in the one-wave kernel of the cart-pole: 512 k against 472 k QP/s).  A compiled kernel is checked
+ * horizon, no register spill in the one-wave kernel of the cart-pole, the compiler's ILP schedule: 563 k against 472 k QP/s).  A compiled kernel is checked
  * against the shipped kernel of the same wave count on the first nodes of its first batch and dropped (message on stderr) if
  * they disagree; HMPC_JIT_SELFCHECK=0 skips the check.
  *   hmpc_kernel_info : which kernel serves the problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming

@@ -3455,8 +3455,9 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     constexpr int RS = KF + KB + KT;
 #if defined(HMPC_SIZED) && !defined(HMPC_DPP_FEW)
     // A kernel compiled with the problem's sizes has the registers for the DPP broadcasts whatever its number of row slots
-    // (one-wave kernel of the headline: 215 AGPRs, no scratch -> 92 B of scratch, +4.6 %; N = 40, two waves: +8.5 %; a shape
-    // compiled at hmpc_create, nx = 6, nu = 2 + 3: +11 %; profiles/r04_dpp_ab.txt)
+    // (N = 40, two waves: +8.5 %; a shape compiled at hmpc_create, nx = 6, nu = 2 + 3: +11 %; one-wave kernel of the headline:
+    // 215 AGPRs, no scratch -> 92 B of scratch, +4.6 % -- but that kernel gains more from the compiler's ILP schedule, which
+    // does not go together with the DPP form: hmpc_jit.h compiles it with -DHMPC_DPP_FEW; profiles/r04_dpp_ab.txt, r04_sched_ab.txt)
     typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0)> D;
 #else
     typedef Dims<NX_, NU_, NUB_, NW, (NX_ > 0 && RS > 0 && RS <= 8)> D;
