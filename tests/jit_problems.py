@@ -13,7 +13,7 @@ import conftest  # noqa: F401  (puts the package on the path)
 from helpers import random_mld, _NoBackend
 
 # (nx, nuc, nub, seed, T): random MLDs of helpers.random_mld
-REGISTER_SHAPES = ((6, 2, 3, 3, 8), (6, 2, 3, 3, 12), (8, 3, 4, 2, 10))
+REGISTER_SHAPES = ((6, 2, 3, 3, 8), (6, 2, 3, 3, 12), (8, 3, 4, 2, 10), (8, 5, 2, 55, 12))   # (the last: test_a_compiled_kernel_that_leaves_nodes_undecided...)
 SIZED = ((20, 6, 8, 0, 30),       # BASELINE configs[4]: beyond one CU's LDS, the streaming form
          (10, 4, 4, 5, 8),        # nx + nu = 18: beyond the static row map, fits LDS (1 / 2 / 4 waves per node)
          (9, 3, 4, 23, 6))        # nx + nu = 16: one more than the register recursions take (found by the first-use check)
