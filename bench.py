@@ -262,11 +262,14 @@ def other_configs(dev):
             gen = HipBatchedQP(cj.problem_data())
         finally:
             del os.environ['HMPC_JIT']
-        rs, _ = _device_rate(spec, x0j, fj, dev)
-        rg, _ = _device_rate(gen, x0j, fj, dev)
+        rs, st_s = _device_rate(spec, x0j, fj, dev)
+        rg, st_g = _device_rate(gen, x0j, fj, dev)
+        # (status ARRAYS, node by node -- round 4 compared counts of optimal / infeasible nodes and missed that the kernel
+        # compiled for the problem left one node undecided and four unpolished; both figures go to `parity_flags`)
         out['generic_vs_specialised'] = {'system': 'random MLD nx=6 nu=2+3 N=12, 2048 random prefixes (p_one 0.3)', 'kernel_kinds_specialised': list(spec.kernel_info()),
                                          'kernel_kinds_generic': list(gen.kernel_info()), 'specialised': rs, 'generic': rg,
-                                         'speedup': rs['qp_per_s'] / rg['qp_per_s'], 'statuses_equal': rs['optimal'] == rg['optimal'] and rs['infeasible'] == rg['infeasible']}
+                                         'speedup': rs['qp_per_s'] / rg['qp_per_s'], 'statuses_equal': bool(np.array_equal(st_s, st_g)),
+                                         'polished_equal': rs['polished'] == rg['polished'], 'compiled_kernels_dropped': int(spec.jit_stats()[0])}
     except Exception as e:
         out['generic_vs_specialised'] = {'error': repr(e)}
     # configs[4]: frontier = prefixes of a dive to a feasible leaf, every other one with a flipped binary (random
@@ -423,6 +426,80 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
         del fl
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'
     return out
+
+
+def fleet_shard(total_loops, world, rank):
+    """Simulations of a study of `total_loops` closed loops that rank `rank` of `world` runs: s = rank, rank + world, ...
+    (simulation s on rank s mod world -- monte_carlo.py; the loops of the reference's study are independent)."""
+    return list(range(rank, total_loops, world))
+
+
+def sharded_fleet_rate(ctrl, world, rank, barrier, dist, dev, total_loops=1024, steps=10, fleet_factory=None, T_state=None):
+    """MPC steps/s of `total_loops` closed loops sharded over the ranks by simulation (simulation s on rank s mod world, as
+    monte_carlo.py and the reference's study, statistical_analysis.py:93-196): one fleet (hmpc_fleet_*) per rank, no
+    communication inside the timed region.  Every rank returns; the figure is the same on all (sum of steps / max wall)."""
+    import torch
+    from helpers import load_fixture
+    x_max = load_fixture('cart_pole_with_walls')['x_max']
+    sims = fleet_shard(total_loops, world, rank)
+    K = len(sims)
+    errs = np.array([0.001 * np.random.RandomState(s).randn(steps + 1, 4) * x_max for s in sims])
+    if fleet_factory is None:
+        from warm_start_hmpc_amd.fleet import FleetMPC
+        fl = FleetMPC(ctrl, K, handdown=True)
+    else:
+        fl = fleet_factory(ctrl, K)            # (the CPU rehearsal of tests/test_distributed.py: the lockstep driver on the oracle)
+    kw = dict(frontier_width=8, speculation=0, cold_speculation=0, cold_frontier_width=8)
+    x0 = np.array([0., 0., 1., 0.]) if T_state is None else np.asarray(T_state, dtype=np.float64)
+    fl.closed_loop(x0, 2, errs[:, :2], **kw)              # warm-up (allocations)
+    barrier()
+    t0 = time.perf_counter()
+    cold = fl.closed_loop(x0, 1, errs[:, :1], **kw)       # the cold-start step alone ...
+    barrier()
+    t_cold = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    st = fl.closed_loop(x0, steps + 1, errs, **kw)         # ... and the same step followed by `steps` warm-started ones
+    barrier()
+    t_all = time.perf_counter() - t0
+    walls = torch.tensor([t_cold, t_all, float(K), float(st['nodes_ws'][:, 1:].sum()), float(st['len_ws'].min()), float(st['len_ws'].max())],
+                         dtype=torch.float64, device=dev if dist.get_backend() == 'nccl' else 'cpu')
+    mx, sm = walls.clone(), walls.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    mn = walls.clone()
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+    loops = int(sm[2].item())
+    dt = float(mx[1].item()) - float(mx[0].item())
+    del fl
+    return {'value': loops * steps / dt, 'unit': 'MPC steps/s (whole job)', 'loops_total': loops, 'loops_per_rank': K, 'steps_timed': steps,
+            'warm_step_ms': 1e3 * dt / steps, 'cold_step_ms': 1e3 * float(mx[0].item()),
+            'warm_solves_per_step_mean': float(sm[3].item()) / (loops * steps), 'cover_min_max': [int(mn[4].item()), int(mx[5].item())],
+            'simulations_of_this_rank': sims[:4] + (['...'] if len(sims) > 4 else []),
+            'sharding': 'simulation s on rank s mod N, one fleet (hmpc_fleet_*) per rank, no collective inside the timed region',
+            'timing': 'barrier + synchronize on both sides, max over the ranks; cold-start step timed apart and subtracted'}
+
+
+def parity_flags(line):
+    """Everything in a bench line that says a kernel did not do what its sibling or the contract says: nodes left undecided
+    (`not_converged` > 0 anywhere), status arrays of two kernels on one workload that differ (`statuses_equal` false), polished
+    counts that differ, compiled kernels the nets dropped.  `ok` is what __graft_entry__.smoke() and the tests hold."""
+    undecided, unequal, dropped = {}, [], {}
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                here = path + [str(k)]
+                if k == 'not_converged' and isinstance(v, (int, float)) and v > 0:
+                    undecided['.'.join(path)] = int(v)
+                elif k in ('statuses_equal', 'polished_equal') and v is False:
+                    unequal.append('.'.join(here))
+                elif k == 'compiled_kernels_dropped' and isinstance(v, (int, float)) and v > 0:
+                    dropped['.'.join(path)] = int(v)
+                else:
+                    walk(v, here)
+    walk(line, [])
+    return {'ok': not undecided and not unequal and not dropped, 'not_converged': undecided, 'statuses_or_polished_counts_differ': unequal,
+            'compiled_kernels_dropped': dropped}
 
 
 def real_tree_frontier(ctrl, B, rank, x_max, spread=0.05, x_center=None):
@@ -682,6 +759,14 @@ def main():
                   'qp_per_s': 1024 * args.steps / float(ts.item()), 'scaling': 'strong',
                   'incumbent': float(ubs.item()), 'note': 'BASELINE configs[2]: 1024-node replay frontier sharded over the ranks, incumbent all-reduce every step'}
 
+    # The other half of BASELINE's metric at N > 1: MPC steps/s of the closed-loop study (statistical_analysis.py:93-196:
+    # independent simulations), sharded by simulation -- simulation s on rank s mod N, no communication (monte_carlo.py) --:
+    # 1024 loops in total, one fleet of 1024 / N loops per rank, disturbances seeded by the GLOBAL simulation index; same
+    # bracketing as the QP metric (barrier + synchronize on both sides, max over the ranks), steps summed over the ranks.
+    fleet_sharded = None
+    if world > 1 and args.workload == 'cart_pole_n20' and not args.no_secondary:
+        fleet_sharded = sharded_fleet_rate(ctrl, world, rank, barrier, dist, dev)
+
     status = out['status'].cpu().numpy()
     raw_iters = out['iters'].cpu().numpy()
     iters = raw_iters & 0xFFFF                           # bits 16..18 flag polished / weak / handed-down records
@@ -739,13 +824,17 @@ def main():
         }
         if strong is not None:
             line['configs2_strong_scaling_1024'] = strong
+        if fleet_sharded is not None:
+            line['mpc_steps_per_sec'] = {'fleet_sharded': fleet_sharded,
+                                         'note': 'closed loop sigma=0.001, warm-started B&B, simulations sharded over the ranks (simulation s on rank s mod N), reference (published, Gurobi): 26.8 steps/s'}
         if world == 1 and args.workload == 'cart_pole_n20':
             try:  # second kernel of the path (HBM bound), a few milliseconds
                 line['warm_start_shift'] = shift_bandwidth(ctrl, dev)
             except Exception as e:
                 line['warm_start_shift'] = {'error': str(e)}
         progress('timed region done: %.3f ms per step' % (1e3 * elapsed / args.steps))
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.workload != 'random_mld':
+            # (rank 0 only; at N > 1 the other ranks have finished their timed regions and wait in the final barrier)
             line['cpu_baseline'] = cpu_baseline(ctrl, x0_h, fix_h)
             progress('cpu baseline done')
         if world == 1 and not args.no_secondary and not args.no_cpu_baseline and args.workload == 'cart_pole_n20':
@@ -756,6 +845,8 @@ def main():
                 except Exception as e:  # secondary figures never hide the main line
                     line[key] = {'error': repr(e)}
                 progress('%s done' % key)
+        line['nodes']['compiled_kernels_dropped'] = int(ctrl.qp.jit_stats()[0])
+        line['parity_flags'] = parity_flags(line)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -51,6 +51,9 @@ extern "C" {
 #define HMPC_ITERS_WEAK 0x20000     /* flag in hmpc_result.iters: HMPC_INFEASIBLE, but the ray is no proof to tolerance */
 #define HMPC_ITERS_TERMINAL 0x80000 /* flag in hmpc_result.iters (launches with hmpc_warm, and large cold batches in the two-launch form): the terminal-set rows were needed */
 #define HMPC_ITERS_HANDED 0x40000   /* flag in hmpc_result.iters: the active set handed down by the parent (hmpc_warm) verified */
+#define HMPC_ITERS_UNCERTIFIED 0x100000 /* flag in hmpc_result.iters, with HMPC_ITERS_WEAK: the node was pruned on the collapse of tau ALONE
+                                         * (tau <= 1e-12 kappa), no ray met even the loose bound of the weak exit -- the drivers count
+                                         * such prunes and say so when one removed a node whose bound lay below the final incumbent */
 
 /* return codes */
 #define HMPC_OK 0
@@ -231,6 +234,10 @@ int hmpc_fleet_solve(hmpc_fleet *f, const double *x0 /* K x nx */, int32_t width
 int hmpc_fleet_shift(hmpc_fleet *f, const double *e0 /* K x nx */, int32_t *cover, int32_t *reopened);
 /* kernel launches (rounds) and nodes sent to the QP kernel since creation */
 int hmpc_fleet_stats(const hmpc_fleet *f, int64_t *rounds, int64_t *launched);
+/* Nodes the fleet's searches pruned WITHOUT a certificate (HMPC_ITERS_UNCERTIFIED), and how many searches ended with such a
+ * node whose bound before its solve lay below the final incumbent (or with no incumbent): there the returned optimum rests on
+ * that prune.  Since creation. */
+int hmpc_fleet_uncertified(const hmpc_fleet *f, int64_t *pruned, int64_t *searches_resting_on_one);
 /* Parent -> child hand-down inside the fleet's searches (hmpc_warm; on by default): a child that is solved in a later
  * round than its parent receives the parent's record, which already lies in the fleet's HBM pools.  enable: 1 / 0, < 0:
  * leave as is.  verified (nullable): solves since creation whose handed-down active set verified. */
@@ -290,29 +297,38 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
                         const double *b, int32_t b_stride, const int32_t *relax, int32_t B, double tol, int32_t max_iter,
                         double *obj, double *x, double *z, int32_t *status, int32_t *iters);
 
-/* Register kernels for any admissible shape.  hmpc_create compiles the fast kernel (static row map: rows and recursions in
- * registers) for a problem whose shape has no built-in instantiation -- the reference takes any MLDSystem,
- * warm_start_hmpc/controller.py:58-117 -- from the sources next to the library, with the offline compiler, into an on-disk
- * cache (csrc/hmpc_jit.h: requirements, environment HMPC_JIT / HMPC_JIT_CACHE / HMPC_HIPCC); shapes outside the static row
- * map's reach, or hosts without a compiler, are served by the run-time-sized kernel.
- * Problems the static row map does not hold (or too large for one CU's LDS) run the run-time-sized kernel / its streaming form
- * COMPILED WITH THE PROBLEM'S SIZES as constants, by the same mechanism (HMPC_JIT_SIZED=0: the shipped kernel): the same
- * code paths, 1.4x on BASELINE configs[4].  The same compilation is applied to the register kernels (exact row slots of the
- * horizon, no register spill in the one-wave kernel of the cart-pole, the compiler's ILP schedule: 563 k against 472 k QP/s).  A compiled kernel is checked
- * against the shipped kernel of the same wave count on the first nodes of its first batch and dropped (message on stderr) if
- * they disagree; HMPC_JIT_SELFCHECK=0 skips the check.
+/* Kernels compiled with the problem's sizes.  The reference takes any MLDSystem at one speed (warm_start_hmpc/controller.py:58-117).
+ * hmpc_create compiles the kernel of each wave count (1 / 2 / 4 waves per node) ONCE MORE for the problem it is given, from the
+ * sources next to the library, with the offline compiler (a child process), its integer sizes as constants of the translation
+ * unit, into an on-disk cache (csrc/hmpc_jit.h: environment HMPC_JIT / HMPC_JIT_SIZED / HMPC_JIT_CACHE / HMPC_HIPCC): the
+ * register kernel (static row map: rows and recursions in registers) where the problem admits it -- nx + nu <= 16, every
+ * [F G] row with at most two input coefficients, columns of at most 16 entries, at most 128 Gram entries with terms, at least
+ * one binary --, the run-time-sized kernel or, beyond one CU's LDS, its streaming form elsewhere.  Same source, same code
+ * paths, same feature set as the shipped kernels, which serve wherever the compilation is not possible (no compiler, no
+ * sources, HMPC_JIT=0 / HMPC_JIT_SIZED=0): the built-in register kernels of the two cart-pole shapes, the run-time-sized kernel
+ * for every other system.
+ * Two nets around code nobody has run before (the reference never hands back an undecided node, bounded_qp.py:216-228):
+ *   first-use check : the first launch through a wave count solves 64 nodes -- spread over its batch, plus the root relaxation
+ *                      and the deepest node -- with the compiled and the shipped kernel and compares statuses and objectives;
+ *                      a kernel that disagrees is dropped for the handle (message on stderr).  One stream synchronisation per
+ *                      wave count, inside that solve call -- or ahead of time through hmpc_validate_kernels (callers that
+ *                      capture their stream or must not block).  HMPC_JIT_SELFCHECK=0 switches both nets off.
+ *   second opinion  : in EVERY solve call (hmpc_solve_batch, hmpc_solve_batch_device, hmpc_fleet_solve) the nodes a compiled
+ *                      kernel leaves MAXITER / NUMERICAL are listed on the device and solved again by the shipped kernel in
+ *                      the same stream, without synchronisation; its records replace theirs.  A compiled kernel that leaves
+ *                      nodes undecided which the shipped kernel decides is dropped when the counts arrive (the next call, or
+ *                      hmpc_second_opinion_review after the caller has synchronised).
  *   hmpc_kernel_info : which kernel serves the problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming
- *                      form, 2 built-in register kernel, 3 register kernel compiled for this shape, 4 / 5 / 6 the run-time-sized
- *                      kernel / its streaming form / the register kernel compiled with this problem's sizes.
+ *                      form, 2 built-in register kernel, 4 / 5 / 6 the run-time-sized kernel / its streaming form / the register
+ *                      kernel compiled with this problem's sizes.
+ *   hmpc_jit_stats   : compiled kernels dropped by the nets; solve calls with a second opinion; batches on which it agreed.
  *   hmpc_jit_build_problem : everything hmpc_create would compile for this problem, ahead of time and without a GPU (the host
- *                      side of hmpc_create, nothing uploaded); paths: the shared objects, newline separated (may be NULL).
- *   hmpc_jit_build   : the same compilation ahead of time, without a GPU (kf / kb / kt: row slots of [F G] rows, bound rows
- *                      and terminal rows per lane, ceil(T / floor(64 nw / nc)), ceil(T / floor(64 nw / (2 nub))), max(1,
- *                      ceil(nT / (64 nw))); kc: longest column of the stage rows, rounded up to even; nw + 8: the build of the
- *                      one-wave kernel for two waves per SIMD, which hmpc_create picks where LDS holds six or more nodes per CU). */
+ *                      side of hmpc_create, nothing uploaded); paths: the shared objects, newline separated (may be NULL). */
 int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3);
-int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len);
+int hmpc_jit_stats(const hmpc_handle *h, int32_t *dropped, int32_t *second_runs, int32_t *second_agreed);
 int hmpc_jit_build_problem(const hmpc_problem *problem, const hmpc_options *options, char *paths, int32_t paths_len);
+int hmpc_validate_kernels(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B, void *stream);
+int hmpc_second_opinion_review(hmpc_handle *h);
 
 /* Number of workgroups the last launch used, and LDS bytes per workgroup (for reports). */
 int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *lds_bytes);

@@ -813,7 +813,8 @@ static int solve_one(const prob_t *p, work_t *k, const double *x0, const int8_t 
              * only: the kernel ran it to 100 iterations, this code left at 37 through (b) by the luck of its rounding).
              * Same conclusion and flag as (c). */
             if ((eta > 0 && tau <= 1e-8 * kap && cert <= 0.5 * eta) || tau <= 1e-12 * kap) {
-                status = ST_INFEASIBLE; weak = 1; break;
+                /* (2: through (d) alone, no ray meets even the bound of (c): flagged UNCERTIFIED for the drivers to count) */
+                status = ST_INFEASIBLE; weak = (eta > 0 && tau <= 1e-8 * kap && cert <= 0.5 * eta) ? 1 : 2; break;
             }
         }
         if (it == max_iter) break;
@@ -929,7 +930,7 @@ output:
         for (int r = 0; r < M; r++) k->z[r] = k->D[r] >= 1.0 ? k->dza[r] : 0.0;
         tau = 1.0;
     }
-    if (polished_out) *polished_out = polished | (weak << 8);
+    if (polished_out) *polished_out = polished | ((weak ? 1 : 0) << 8) | ((weak == 2 ? 1 : 0) << 10);
 
     /* ---- outputs in the reference's conventions ---- */
     int nmu = (T - 1) * p->nc + p->ncL;

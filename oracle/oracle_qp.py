@@ -101,5 +101,6 @@ class OracleBatchedQP(object):
         out['time'] = time.perf_counter() - tic
         out['weak'] = (out['polished'] >> 8) & 1        # infeasible, but the ray is no proof to tolerance (HMPC_ITERS_WEAK)
         out['second'] = (out['polished'] >> 9) & 1      # the terminal-set rows were needed: the node was solved twice (lazy terminal set)
+        out['uncertified'] = (out['polished'] >> 10) & 1  # weak, and pruned on the collapse of tau alone (HMPC_ITERS_UNCERTIFIED)
         out['polished'] &= 0xff
         return out

@@ -1,5 +1,6 @@
 """Diagnostic: variants of the kernels of a problem whose compiled kernels came out wrong (see gpu_dev_selfcheck_case.py; like it,
-it reproduces only before the static row map was cut back to nx + nu <= 15: profiles/r04_nz16_register_kernels.txt)."""
+it reproduced only before the static row map was cut back to nx + nu <= 15: profiles/r04_nz16_register_kernels.txt; round 5:
+the cause was the LDS carve of the register kernels at nz >= 16, fixed, nx + nu = 16 is admitted again).  DBG_ONLY="label;label"."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +28,11 @@ for spec in SPECS:
     b = orc.solve_batch(x0, fix)
     for label, env in (('sized', {}), ('sized, readlane broadcasts', {'HMPC_JIT_FLAGS': '-DHMPC_DPP_FEW'}), ('sized, default schedule', {'HMPC_JIT_SCHED': 'default'}),
                        ('sized, -O1', {'HMPC_JIT_FLAGS': '-O1'}), ('per shape', {'HMPC_JIT_SIZED': '0'}),
-                       ('sized, no VGPR -> AGPR spilling', {'HMPC_JIT_FLAGS': '-mllvm -amdgpu-spill-vgpr-to-agpr=0'}))[(int(os.environ.get('DBG_FROM', 0))):]:
+                       ('sized, no VGPR -> AGPR spilling', {'HMPC_JIT_FLAGS': '-mllvm -amdgpu-spill-vgpr-to-agpr=0'}),
+                       ('sized, no stack slot sharing', {'HMPC_JIT_FLAGS': '-mllvm -no-stack-slot-sharing'}),
+                       ('sized, stack slot colouring off', {'HMPC_JIT_FLAGS': '-mllvm -disable-ssc'}))[(int(os.environ.get('DBG_FROM', 0))):]:
+        if os.environ.get('DBG_ONLY') and label not in os.environ['DBG_ONLY'].split(';'):
+            continue
         os.environ.update(env)
         hip = HipBatchedQP(ctrl.problem_data())
         for k in env:

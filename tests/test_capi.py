@@ -90,31 +90,50 @@ def test_c_caller_gets_the_known_answers(tmp_path):
     assert r.returncode == 0 and 'c_abi_example: ok' in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
-def test_headline_kernel_keeps_its_register_budget(tmp_path):
-    # The one-wave-per-node kernel of the cart-pole shape lives at the edge of the register file (256 + 256 registers per
-    # lane, ~120 B of scratch): three times this round an edit that only added a flag or a branch elsewhere moved its
-    # register allocation and cost 6-8 % of every launch.  The scratch size of that instantiation, as the
-    # compiler reports it, is held here (cross-compiles without a GPU, ~15 s).
+def test_headline_kernel_keeps_its_register_budget(tmp_path, monkeypatch):
+    # The one-wave-per-node kernel of the cart-pole at N = 20 -- the kernel the bench line runs on, compiled with the problem's
+    # sizes (csrc/hmpc_jit.h) -- lives at the edge of the register file (256 + ~246 registers per lane): edits that only added a
+    # flag or a branch elsewhere have moved its register allocation and cost 6-8 % of every launch.  Its scratch
+    # size, as the compiler reports it, is held at ZERO here (cross-compiles without a GPU, ~30 s): the exact command of
+    # hmpc_create, caught through HMPC_HIPCC, run once more with -Rpass-analysis=kernel-resource-usage.
     import re
+    import stat
     import subprocess
+    from helpers import make_controller, _NoBackend
+    from warm_start_hmpc_amd.qp_backend import jit_prebuild
+    wrap = tmp_path / 'hipcc_wrap.sh'
+    wrap.write_text('#!/bin/bash\necho "$@" >> %s/commands.txt\nfor a in "$@"; do case "$a" in *.hip) cp "$a" %s/ ;; esac; done\nexec /opt/rocm/bin/hipcc "$@"\n' % (tmp_path, tmp_path))
+    wrap.chmod(wrap.stat().st_mode | stat.S_IEXEC)
+    cache = tmp_path / 'cache'
+    cache.mkdir(mode=0o755)
+    monkeypatch.setenv('HMPC_HIPCC', str(wrap))
+    monkeypatch.setenv('HMPC_JIT_CACHE', str(cache))
+    paths = jit_prebuild(make_controller('cart_pole_with_walls', T=20, backend=_NoBackend()).problem_data())
+    assert len(paths) == 3
+    cmds = [c for c in (tmp_path / 'commands.txt').read_text().splitlines() if '_w1_' in c]
+    assert len(cmds) == 1 and 'hmpc_s_reg_4_7_4_10_3_2_w1_kc14' in cmds[0] and '-no-stack-slot-sharing' in cmds[0] and '-disable-copyprop' in cmds[0]
+    unit = [f for f in os.listdir(tmp_path) if f.endswith('.hip') and '_w1_' in f]
+    assert len(unit) == 1
+    args = [a for a in cmds[0].split() if not a.endswith('.hip') and not a.endswith('.tmp.so') and a not in ('-shared', '-o', '-Wl,-Bsymbolic')]
+    r = subprocess.run(['/opt/rocm/bin/hipcc'] + args + ['--cuda-device-only', '-c', str(tmp_path / unit[0]), '-o', str(tmp_path / 'probe.o'),
+                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    names = re.findall(r'Function Name: (\S+)', r.stderr)
+    scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
+    assert len(names) == len(scratch) == 2, (names, scratch)
+    cold = [s for n, s in zip(names, scratch) if 'Lb0E' in n]                # (the kernel without the hand-down code: the headline)
+    assert cold == [0], (names, scratch)
+    assert max(scratch) <= 64, scratch                                       # (its hand-down instantiation: 20 B)
+    # The streaming form of the generic kernel (BASELINE configs[4]) must not spill at all in its shipped build: a second
+    # instantiation of its tile code once cost the whole kernel 650 B of scratch per lane -- 134 KB per workgroup pushed
+    # through an L2 the factor slabs already overflow.
     csrc = os.path.join(ROOT, 'warm-start-hybrid-mpc_amd', 'csrc')
     src = tmp_path / 'probe.hip'
-    src.write_text('#define HMPC_KERNEL_ONLY\n#include "hmpc_device.h"\n#include "hmpc_kernel.hip"\n'
-                   'template __global__ void hmpc_qp_kernel<4, 7, 4, 10, 3, 2, 1>(const DevProb, const double *, int, const int8_t *, int, '
-                   'const DevOut, double *, double *, const int32_t *, const DevWarm);\n')
-    r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-Wno-pass-failed',
-                        '-I', os.path.join(ROOT, 'include'), '-I', csrc, '-c', str(src), '-o', str(tmp_path / 'probe.o'),
-                        '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    scratch = [int(v) for v in re.findall(r'ScratchSize \[bytes/lane\]: (\d+)', r.stderr)]
-    assert scratch and max(scratch) <= 128, scratch
-    # The streaming form of the generic kernel (BASELINE configs[4]) must not spill at all: a second instantiation of its
-    # tile code once cost the whole kernel 650 B of scratch per lane -- 134 KB per workgroup pushed through an L2 the
-    # factor slabs already overflow.
     src.write_text('#define HMPC_KERNEL_ONLY\n#include "hmpc_device.h"\n#include "hmpc_kernel.hip"\n'
                    'template __global__ void hmpc_qp_kernel<-1, 0, 0, 0, 0, 0, 4>(const DevProb, const double *, int, const int8_t *, int, '
                    'const DevOut, double *, double *, const int32_t *, const DevWarm);\n')
     r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-Wno-pass-failed',
+                        '-mllvm', '-no-stack-slot-sharing', '-mllvm', '-disable-copyprop',
                         '-I', os.path.join(ROOT, 'include'), '-I', csrc, '-c', str(src), '-o', str(tmp_path / 'probe.o'),
                         '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -122,31 +141,24 @@ def test_headline_kernel_keeps_its_register_budget(tmp_path):
     assert scratch and max(scratch) == 0, scratch
 
 
-def test_register_kernel_is_compiled_for_an_arbitrary_shape(monkeypatch):
-    # The reference takes any MLDSystem (warm_start_hmpc/controller.py:58-117); the fast kernel here is a compile-time
-    # instantiation.  For a shape without a built-in one hmpc_create compiles it from the same source into an on-disk
-    # cache (csrc/hmpc_jit.h); hmpc_jit_build does the same without a GPU.  A random MLD with nx = 6, nu = 2 + 3 -- three
-    # binaries: their six bound rows do not tile a wavefront --: four shared objects (1 / 2 / 4 waves per node, the one-wave
-    # kernel also built for two waves per SIMD), each
-    # exporting the getter of its two kernels; a second call is a cache hit.
-    import time
-    from helpers import random_mld, _NoBackend
-    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
-    from warm_start_hmpc_amd.qp_backend import jit_shapes, jit_prebuild
-    monkeypatch.setenv('HMPC_JIT_SIZED', '0')      # (the per-shape kernels; the default -- per problem -- in the next test)
-    mld, objective, x0 = random_mld(nx=6, nuc=2, nub=3, seed=3)
-    ctrl = HybridModelPredictiveController(mld, 8, objective, None, backend=_NoBackend())
-    shapes = jit_shapes(ctrl.problem_data())
-    assert [s[:3] + s[6:] for s in shapes] == [(6, 5, 3, 1, 8), (6, 5, 3, 2, 8), (6, 5, 3, 4, 8)]
-    paths = jit_prebuild(ctrl.problem_data())
-    assert len(paths) == 4 and all(os.path.exists(p) for p in paths)      # (1 wave: also its build for two waves per SIMD)
-    for p in paths:
-        assert hasattr(ctypes.CDLL(p), 'hmpc_jit_kernels')
-    tic = time.perf_counter()
-    assert jit_prebuild(ctrl.problem_data()) == paths and time.perf_counter() - tic < 2.0      # (cache hits)
-    # shapes the static row map does not hold, and the built-in ones, are not compiled
-    big = HybridModelPredictiveController(random_mld()[0], 30, random_mld()[1], None, backend=_NoBackend())
-    assert jit_shapes(big.problem_data()) == []
+def test_only_kernels_compiled_with_a_problems_sizes_exist(monkeypatch, tmp_path):
+    # ONE family of compiled kernels (round 5): hmpc_create compiles per PROBLEM; the kernels per SHAPE of round 4's first form
+    # (HMPC_JIT_SIZED=0 used to select them) are gone -- with HMPC_JIT_SIZED=0 or HMPC_JIT=0 nothing is compiled and the shipped
+    # kernels serve.  Every cache entry carries the one prefix.
+    from jit_problems import problem, REGISTER_SHAPES
+    from warm_start_hmpc_amd.qp_backend import jit_prebuild
+    data = problem(*REGISTER_SHAPES[0])[0]
+    monkeypatch.setenv('HMPC_JIT_CACHE', str(tmp_path))
+    monkeypatch.setenv('HMPC_JIT_SIZED', '0')
+    assert jit_prebuild(data) == [] and os.listdir(tmp_path) == []
+    monkeypatch.delenv('HMPC_JIT_SIZED')
+    monkeypatch.setenv('HMPC_JIT', '0')
+    assert jit_prebuild(data) == [] and os.listdir(tmp_path) == []
+    monkeypatch.delenv('HMPC_JIT')
+    monkeypatch.delenv('HMPC_JIT_CACHE')
+    paths = jit_prebuild(data)
+    assert len(paths) == 3 and all(os.path.basename(p).startswith('hmpc_s_') for p in paths)
+    assert not hasattr(ctypes.CDLL(os.path.join(ROOT, 'warm-start-hybrid-mpc_amd', 'libhmpc.so')), 'hmpc_jit_build')
 
 
 def test_run_time_sized_kernel_is_compiled_with_the_sizes_of_a_problem():

@@ -202,3 +202,56 @@ def test_strong_scaling_frontier_of_the_bench_under_gloo():
     assert np.array_equal(merged, ref['obj'])                           # ... that cover the frontier; same records
     full = (fix_all >= 0).all(axis=1) & (ref['status'] == 0)
     assert got[0][3] == got[1][3] == ref['obj'][full].min()             # the same global incumbent on both ranks
+
+
+class _LockstepOnTheOracle(object):
+    """What bench.sharded_fleet_rate needs of a fleet (closed_loop -> nodes_ws, len_ws as arrays), on the numpy lockstep
+    driver over the CPU oracle: the rehearsal of the sharded closed-loop leg of the bench line."""
+
+    def __init__(self, ctrl, K):
+        from warm_start_hmpc_amd.batched import BatchedMPC
+        self.driver, self.K = BatchedMPC(ctrl), K
+
+    def closed_loop(self, x0, n_steps, errors, frontier_width=8, **_):
+        st = self.driver.closed_loop(x0, n_steps, seeds=tuple(range(self.K)), frontier_width=frontier_width, errors=errors)
+        return dict(nodes_ws=np.array(st['nodes_ws']), len_ws=np.array(st['len_ws']), wall=st['wall'])
+
+
+def _sharded_fleet_worker(rank, world, port, q):
+    # the `mpc_steps_per_sec.fleet_sharded` key of a multi-GPU bench line (bench.sharded_fleet_rate: simulations sharded over the
+    # ranks, barriers around the timed regions, MAX of the wall times, SUM of the steps), rehearsed under gloo on the oracle
+    for p in (ROOT, os.path.join(ROOT, 'warm-start-hybrid-mpc_amd'), os.path.join(ROOT, 'tests')):
+        sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import bench
+    from helpers import make_controller
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle', threads=2)
+    r = bench.sharded_fleet_rate(ctrl, world, rank, dist.barrier, dist, 'cpu', total_loops=5, steps=2, fleet_factory=_LockstepOnTheOracle,
+                                 T_state=[0., 0., .5, 0.])
+    q.put((rank, r))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_closed_loops_of_the_bench_under_gloo():
+    import bench
+    assert bench.fleet_shard(5, 2, 0) == [0, 2, 4] and bench.fleet_shard(5, 2, 1) == [1, 3]
+    assert sorted(s for r in range(8) for s in bench.fleet_shard(1024, 8, r)) == list(range(1024))
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_fleet_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    a, b = got[0][1], got[1][1]
+    # every rank reports the whole job: 5 loops, the same rate, the published cover of the warm-started steps
+    assert a['loops_total'] == b['loops_total'] == 5 and a['loops_per_rank'] == 3 and b['loops_per_rank'] == 2
+    assert a['value'] == b['value'] > 0 and a['steps_timed'] == 2
+    assert a['warm_solves_per_step_mean'] == b['warm_solves_per_step_mean'] and 5 <= a['warm_solves_per_step_mean'] <= 30
+    assert a['cover_min_max'] == b['cover_min_max']

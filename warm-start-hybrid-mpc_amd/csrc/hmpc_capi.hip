@@ -20,7 +20,7 @@
 #include "hmpc_jit.h"      // register kernels for shapes without a built-in instantiation, compiled at hmpc_create
 #include "hmpc_shift.hip"
 
-#define HMPC_CHECK_NODES 6 // (even) nodes of the first-use check of a kernel compiled at hmpc_create (hmpc_check_compiled)
+#define HMPC_CHECK_NODES 64 // (even) nodes of the first-use check of a kernel compiled at hmpc_create (hmpc_check_compiled)
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg)
 {
@@ -46,7 +46,7 @@ struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve
     size_t ref_lds = 0;
     int ref_grid = 0;
     int checked = 0; // 0 not yet, 1 agreed, -1 disagreed (ref serves)
-    int second_opinions = 0; // batches with MAXITER / NUMERICAL nodes that the shipped kernel solved again and ended the same way (hmpc_solve_batch)
+    int second_opinions = 0; // batches with MAXITER / NUMERICAL nodes that the shipped kernel solved again and ended the same way (hmpc_solve_batch_device)
 };
 
 struct hmpc_handle {
@@ -71,7 +71,16 @@ struct hmpc_handle {
     int staged = 0;
     bool staged_warm = false; // the blocks have room for one handed-down parent record per node
     int last_cfg = -1;            // configuration (0, 1, 2: 1 / 2 / 4 waves per node) of the last launch
-    bool use_ref = false;         // the next launch runs the shipped kernel of its configuration (second opinion, hmpc_solve_batch)
+    // SECOND OPINION (hmpc_solve_batch_device): nodes a compiled kernel leaves undecided are listed on the device and solved again
+    // by the shipped kernel in the same stream.  hard: [0] how many of them the shipped kernel leaves undecided too, [1] its work
+    // counter, [2] how many the compiled kernel left, [3 ..] which.  The two counts of the last call travel to h_hard (pinned)
+    // behind hard_done and are looked at when the next call comes, or when a caller that has synchronised asks (hmpc_second_opinion_review).
+    int32_t *hard = nullptr;
+    int hard_cap = 0;
+    int32_t *h_hard = nullptr;
+    hipEvent_t hard_done = nullptr;
+    int hard_cfg = -1;            // configuration the counts in flight belong to (-1: none)
+    int second_runs = 0;          // calls in which the shipped kernel was asked (for the tests)
     void *chk = nullptr;          // device block of the first-use check: 2 x HMPC_CHECK_NODES x (obj, dual_obj, status, iters)
     int jit_rejected = 0;         //   compiled kernels dropped by it
     std::vector<void *> jit_libs; // shared objects of kernels compiled for this problem's shape (hmpc_jit.h); never unloaded
@@ -169,53 +178,26 @@ int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
     return HMPC_OK;
 }
 
-// Register kernels of this problem's shape for 1 / 2 / 4 waves per node, compiled or fetched from the cache (hmpc_jit.h).
-// Shapes with a built-in instantiation, shapes the static row map does not hold, and hosts without a compiler leave jit
-// empty: hmpc_pick_kernel then takes what it always took.
-// shapes_only: nothing is built -- jit gets placeholders (waves, kc, occ2) for hmpc_pick_kernel; the kernels that run are then
-// compiled WITH THE PROBLEM'S SIZES by hmpc_jit_prepare_sized.
-void hmpc_jit_prepare(const DevProb &p, hmpc_kernel_choice (&jit)[3], std::vector<void *> &libs, size_t lds_cu, std::vector<std::string> *built, bool shapes_only)
+// Wave counts for which this problem gets a register kernel compiled with its sizes (hmpc_jit_prepare_sized): placeholders
+// (waves, kc, occ2) for hmpc_pick_kernel where the static row map holds the problem -- nx + nu <= 16, every [F G] row with
+// at most two input coefficients, columns of at most HMPC_KC_STRIDE entries, at most 128 Gram entries with terms, at least one
+// binary, at most 16 row slots per lane.  The two cart-pole shapes have built-in instantiations, which hmpc_pick_kernel finds
+// itself; other problems leave jit empty and take the run-time-sized kernel.
+void hmpc_jit_register_shapes(const DevProb &p, hmpc_kernel_choice (&jit)[3], size_t lds_cu)
 {
     if (getenv("HMPC_FORCE_GENERIC") || getenv("HMPC_FORCE_BIG")) return;
     if ((p.nx == 4 && p.nu == 7 && p.nub == 4) || (p.nx == 4 && p.nu == 4 && p.nub == 2)) return; // (built in)
-    if (!p.static_rows || p.nz > 15 || p.nub < 1) return; // (nz = 16: see factor_reg)
+    if (!p.static_rows || p.nz > 16 || p.nub < 1) return;
     const int kc = std::max(2, (p.kcol + 1) / 2 * 2);
     if (kc > HMPC_KC_STRIDE || hmpc_lds_bytes(p, kc, 0) > lds_cu) return;
-    hmpc_jit_shape shapes[3];
-    int slot[3], count = 0;
     for (int c = 0; c < 3; c++) {
         int kf = 0, kb = 0, kt = 0;
         if (!hmpc_static_slots(p, 1 << c, kf, kb, kt)) continue;
         if (kt < 1) kt = 1;                 // (the row map keeps a terminal slot; a problem without terminal set leaves it empty)
         if (kf + kb + kt > 16) continue;    // (row state in registers: 4 doubles per slot and lane)
-        shapes[count] = {p.nx, p.nu, p.nub, kf, kb, kt, 1 << c, kc, (c == 0 && lds_cu / hmpc_lds_bytes(p, kc, 0) >= 6 && !getenv("HMPC_JIT_NO_OCC2")) ? 1 : 0};
-        slot[count++] = c;
+        const int occ2 = (c == 0 && lds_cu / hmpc_lds_bytes(p, kc, 0) >= 6 && !getenv("HMPC_JIT_NO_OCC2")) ? 1 : 0;
+        jit[c] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, 1 << c, kc, 0, occ2};
     }
-    if (!count) return;
-    if (shapes_only) {
-        for (int i = 0; i < count; i++) jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0, shapes[i].occ2};
-        return;
-    }
-    std::vector<std::string> paths;
-    std::string err;
-    (void)hmpc_jit_build_all(shapes, count, paths, err);
-    for (int i = 0; i < count; i++) {
-        if (paths[i].empty()) continue;
-        if (built) {                                                     // (dry run: built, not loaded; the choice of kernels must still see it)
-            built->push_back(paths[i]);
-            jit[slot[i]] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, shapes[i].nw, kc, 0, shapes[i].occ2};
-            continue;
-        }
-        void *lib = dlopen(paths[i].c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!lib) { err = std::string("dlopen: ") + dlerror(); continue; }
-        auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
-        if (!get) { err = "hmpc_jit_kernels not found in " + paths[i]; continue; }
-        void *cold = nullptr, *warm = nullptr;
-        get(&cold, &warm);
-        libs.push_back(lib);
-        jit[slot[i]] = {(hmpc_kernel_t)cold, (hmpc_kernel_t)warm, shapes[i].nw, kc, 0, shapes[i].occ2};
-    }
-    if (!err.empty() && getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: register kernel for this shape not available (%s): the run-time-sized kernel serves it\n", err.c_str());
 }
 
 // The integer sizes of a problem as assignments to the fields of DevProb: the body of HMPC_SIZED(p) of a kernel compiled for
@@ -310,24 +292,6 @@ bool hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
 } // namespace
 
 extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
-
-// Compiles (or finds in the cache) the register kernel of one shape without touching a GPU: what hmpc_create does for a
-// shape without a built-in instantiation, callable ahead of time (packaging, warming the cache of a machine without a
-// compiler from one that has it).  path: where the shared object lies (may be NULL).
-extern "C" int hmpc_jit_build(int32_t nx, int32_t nu, int32_t nub, int32_t kf, int32_t kb, int32_t kt, int32_t nw, int32_t kc, char *path, int32_t path_len)
-{
-    g_err.clear();
-    if (nx < 1 || nu < 1 || nub < 1 || nub > nu || nx + nu > 15 || kf < 1 || kb < 1 || kt < 1 || kf + kb + kt > 16 || ((nw & 7) != 1 && (nw & 7) != 2 && (nw & 7) != 4) || (nw & ~15) || kc < 2 ||
-        kc > HMPC_KC_STRIDE || (kc & 1))
-        return fail(HMPC_EINVAL, "jit: not a shape of the static row map");
-    hmpc_jit_shape s{nx, nu, nub, kf, kb, kt, nw & 7, kc, (nw & 8) ? 1 : 0}; // (nw + 8: the two-waves-per-SIMD build of the one-wave kernel)
-    nw &= 7;
-    std::vector<std::string> paths;
-    std::string err;
-    if (!hmpc_jit_build_all(&s, 1, paths, err) || paths[0].empty()) return fail(HMPC_EDEVICE, "jit: " + err);
-    if (path && path_len > 0) snprintf(path, (size_t)path_len, "%s", paths[0].c_str());
-    return HMPC_OK;
-}
 
 // hmpc_create; with `built` the DRY form behind hmpc_jit_build_problem: the same host code up to the choice of kernels --
 // which compiles what this problem's kernels need into the cache -- without a device: nothing is uploaded, no handle returned.
@@ -566,12 +530,14 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
     // one kernel per number of waves per node; each has its own LDS carve and resident-node count
     const char *env = getenv("HMPC_BLOCKS_PER_CU");
     for (int pass = 0; pass < 2; pass++) {
-        // first the kernels compiled with this problem's sizes (hmpc_jit.h); without them (HMPC_JIT_SIZED=0, no compiler at run
-        // time) the shipped kernels and, for other shapes of the static row map, register kernels compiled per shape
+        // first the kernels compiled with this problem's sizes (hmpc_jit.h); without them (HMPC_JIT_SIZED=0 / HMPC_JIT=0, no
+        // compiler at run time, a compilation that fails) the shipped kernels: the built-in register kernels of the two
+        // cart-pole shapes, the run-time-sized kernel for every other system
         const bool sized = pass == 0 && hmpc_sized_enabled();
         if (pass == 0 && !sized) continue;
         for (int c = 0; c < 3; c++) { jit[c] = hmpc_kernel_choice{}; h->cfg[c] = hmpc_cfg{}; }
-        hmpc_jit_prepare(p, jit, h->jit_libs, lds_cu, built, sized);
+        h->jit_kernels = 0; // (kernels of a first pass that did not complete are not in use)
+        if (sized) hmpc_jit_register_shapes(p, jit, lds_cu);
         for (int c = 0; c < 3; c++) {
             hmpc_cfg &cf = h->cfg[c];
             cf.k = hmpc_pick_kernel(p, 1 << c, jit);
@@ -588,10 +554,28 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
     if (dry) { delete h; return HMPC_OK; }
     for (int c = 0; c < 3; c++) {
         hmpc_cfg &cf = h->cfg[c];
-        if (hipFuncSetAttribute((const void *)cf.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)cf.k.fn_warm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cf.lds) != hipSuccess) {
-            hmpc_destroy(h);
-            return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
+        auto reserve = [](const hmpc_cfg &f) {
+            return hipFuncSetAttribute((const void *)f.k.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds) == hipSuccess &&
+                   hipFuncSetAttribute((const void *)f.k.fn_warm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f.lds) == hipSuccess;
+        };
+        if (!reserve(cf)) {
+            // a kernel from the cache that this device does not take (a stale or foreign object: another architecture, another
+            // runtime): the shipped kernel of the wave count serves instead, as after a failed first-use check
+            const hmpc_kernel_choice ship = hmpc_pick_kernel(p, 1 << c, nullptr);
+            bool ok = false;
+            if (ship.fn != cf.k.fn) {
+                (void)hipGetLastError();
+                if (getenv("HMPC_JIT_VERBOSE")) fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) cannot be set up on this device: the shipped kernel serves\n", cf.k.waves);
+                cf.k = ship;
+                cf.lds = hmpc_lds_bytes(p, ship.kc, ship.big);
+                cf.sized = 0;
+                h->jit_rejected++;
+                ok = cf.lds <= lds_cu && (lds_max <= 0 || cf.lds <= (size_t)lds_max) && reserve(cf);
+            }
+            if (!ok) {
+                hmpc_destroy(h);
+                return fail(HMPC_EDEVICE, "cannot reserve dynamic LDS for the kernel");
+            }
         }
         int per_cu = (int)(lds_cu / cf.lds);
         if (per_cu > 8) per_cu = 8;
@@ -600,7 +584,6 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
         if (cf.max_grid > h->max_grid) h->max_grid = cf.max_grid;
     }
     h->lds = h->cfg[0].lds;
-    for (int c = 0; c < 3; c++) h->jit_kernels += jit[c].fn != nullptr && h->cfg[c].k.fn == jit[c].fn;
     // kernels compiled at hmpc_create are checked against the shipped kernel of the same wave count at their first launch
     bool ref_big = false;
     {
@@ -622,10 +605,21 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
             ref_big = ref_big || ref.big;
         }
         // ((obj, dual_obj) x 3 runs, (status, iters) x 3 runs, the hand-down index, the records of the compiled kernel's cold run)
+        // ... and the check's own nodes: initial states and fixing vectors (hmpc_check_set_kernel)
         if (hipMalloc(&h->chk, 3 * HMPC_CHECK_NODES * 2 * sizeof(double) + 3 * HMPC_CHECK_NODES * 2 * sizeof(int32_t) + HMPC_CHECK_NODES * sizeof(int32_t) +
-                                   (size_t)HMPC_CHECK_NODES * (p.n_primal + p.n_dual) * sizeof(double)) != hipSuccess) {
+                                   (size_t)HMPC_CHECK_NODES * (p.n_primal + p.n_dual + p.nx) * sizeof(double) + (size_t)HMPC_CHECK_NODES * p.T * p.nub + 64) != hipSuccess) {
             hmpc_destroy(h);
             return fail(HMPC_EDEVICE, "cannot allocate the check block");
+        }
+        // second opinion of hmpc_solve_batch_device: its counts travel to two pinned words behind an event
+        bool any_ref = false;
+        for (int c = 0; c < 3; c++) any_ref = any_ref || h->cfg[c].ref.fn != nullptr;
+        if (any_ref && on) {
+            if (hipHostMalloc((void **)&h->h_hard, 2 * sizeof(int32_t), hipHostMallocDefault) != hipSuccess ||
+                hipEventCreateWithFlags(&h->hard_done, hipEventDisableTiming) != hipSuccess) {
+                hmpc_destroy(h);
+                return fail(HMPC_EDEVICE, "cannot allocate the second-opinion block");
+            }
         }
     }
     p.fac_ws = nullptr;
@@ -686,6 +680,9 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->pend) (void)hipFree(h->pend);
     if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->chk) (void)hipFree(h->chk);
+    if (h->hard) (void)hipFree(h->hard);
+    if (h->h_hard) (void)hipHostFree(h->h_hard);
+    if (h->hard_done) (void)hipEventDestroy(h->hard_done);
     if (h->trace) (void)hipFree(h->trace);
     if (h->d_x0) (void)hipFree(h->d_x0);
     if (h->h_stage) (void)hipHostFree(h->h_stage);
@@ -694,22 +691,26 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
 }
 
 // Which kind of kernel serves this problem, per waves per node (1, 2, 4): 0 run-time-sized, 1 its streaming form,
-// 2 built-in register kernel, 3 register kernel compiled for this shape at hmpc_create, 4 / 5 / 6 the run-time-sized kernel /
-// its streaming form / the register kernel compiled with this problem's sizes at hmpc_create.
+// 2 built-in register kernel, 4 / 5 / 6 the run-time-sized kernel / its streaming form / the register kernel compiled with
+// this problem's sizes at hmpc_create (3, the register kernel compiled per SHAPE of round 4, no longer exists).
 extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
 {
     if (!h || !kind3) return fail(HMPC_EINVAL, "null argument");
     for (int c = 0; c < 3; c++) {
         const hmpc_kernel_choice &k = h->cfg[c].k;
-        bool jitted = false;
-        for (void *lib : h->jit_libs) {
-            auto get = (void (*)(void **, void **))dlsym(lib, "hmpc_jit_kernels");
-            void *a = nullptr, *b = nullptr;
-            if (get) get(&a, &b);
-            jitted |= a == (void *)k.fn;
-        }
-        kind3[c] = k.kc > 0 ? (h->cfg[c].sized ? 6 : jitted ? 3 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
+        kind3[c] = k.kc > 0 ? (h->cfg[c].sized ? 6 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
     }
+    return HMPC_OK;
+}
+
+// Compiled kernels of this handle: how many were dropped by the first-use check or the second opinion, in how many solve calls
+// the shipped kernel was asked for a second opinion, and on how many of those batches it ended like the compiled one.
+extern "C" int hmpc_jit_stats(const hmpc_handle *h, int32_t *dropped, int32_t *second_runs, int32_t *second_agreed)
+{
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    if (dropped) *dropped = h->jit_rejected;
+    if (second_runs) *second_runs = h->second_runs;
+    if (second_agreed) *second_agreed = h->cfg[0].second_opinions + h->cfg[1].second_opinions + h->cfg[2].second_opinions;
     return HMPC_OK;
 }
 
@@ -846,30 +847,37 @@ extern "C" int hmpc_launch_info(const hmpc_handle *h, int32_t *grid, int32_t *ld
 }
 
 // FIRST-USE CHECK of a kernel compiled at hmpc_create (hmpc_cfg::ref).  The run-time compiler produces code nobody has run
-// before for a problem nobody has seen -- and this kernel lives at the edge of the register file, where a diagnostic variant
-// of the configs[4] kernel was once seen to come out wrong from the compiler's VGPR -> AGPR spilling (correct with
-// -amdgpu-spill-vgpr-to-agpr=0 and at -O1; profiles/r04_check_build.txt).  So the first launch through a configuration solves
-// the first few nodes of ITS batch with the compiled kernel and with the shipped kernel of the same wave count, and compares
-// statuses and objectives (1e-6 relative: the two are the same algorithm).  Agreement: the compiled kernel serves from then
-// on.  Disagreement: it is dropped for this handle, loudly.  One stream synchronisation, once per configuration.
+// before for a problem nobody has seen -- and this kernel lives at the edge of the register file (round 5 traced the wrong
+// binaries of round 4 to the compiler's stack-slot colouring of spilled scalars: DESIGN.md 4.8).  So the first launch through a
+// configuration solves HMPC_CHECK_NODES nodes -- spread over ITS batch, plus the root relaxation and the deepest node of the
+// batch's first initial state (hmpc_check_set_kernel) -- with the compiled kernel and with the shipped kernel of the same wave
+// count, and compares statuses and objectives (1e-6 relative: the two are the same algorithm).  Agreement: the compiled
+// kernel serves from then on.  Disagreement: it is dropped for this handle, loudly.  One stream synchronisation, once per
+// configuration (hmpc_validate_kernels runs it ahead of time: a caller that captures its stream, or must not block in a solve call).
 static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0, int x0_stride, const int8_t *d_fix, int B, hipStream_t stream)
 {
     cf.checked = 1;
     if (!cf.ref.fn || !h->chk || h->trace) return HMPC_OK;
-    if (getenv("HMPC_JIT_SELFCHECK_SKIP_FIRST")) return HMPC_OK; // (test hook: leaves a wrong kernel to the second opinion of hmpc_solve_batch)
-    const int nb = B < HMPC_CHECK_NODES ? B : HMPC_CHECK_NODES;
+    if (getenv("HMPC_JIT_SELFCHECK_SKIP_FIRST")) return HMPC_OK; // (test hook: leaves a wrong kernel to the second opinion of hmpc_solve_batch_device)
     constexpr int N = HMPC_CHECK_NODES;
+    const DevProb &p = h->dp;
+    const int nfix = p.T * p.nub;
     double *obj = (double *)h->chk, *dobj = obj + 3 * N;
     int32_t *st = (int32_t *)(dobj + 3 * N), *it = st + 3 * N, *idx = it + 3 * N;
-    double *prim = (double *)(idx + N + (N & 1)), *dual = prim + (size_t)N * h->dp.n_primal; // (N even: the records stay 8-byte aligned)
+    double *prim = (double *)(idx + N + (N & 1)), *dual = prim + (size_t)N * p.n_primal; // (N even: the records stay 8-byte aligned)
+    double *x0c = dual + (size_t)N * p.n_dual;
+    int8_t *fixc = (int8_t *)(x0c + (size_t)N * p.nx);
+    hipLaunchKernelGGL(hmpc_check_set_kernel, dim3(N), dim3(256), 0, stream, d_x0, x0_stride, d_fix, B, nfix, p.nx, N, x0c, fixc);
+    HIPCHK(hipGetLastError());
     const DevWarm w{nullptr, nullptr, nullptr, nullptr, 0};
     // runs 0 / 1: the shipped and the compiled kernel, cold (the compiled one keeps its records for run 2)
     for (int which = 0; which < 2; which++) {
         const hmpc_kernel_choice &k = which ? cf.k : cf.ref;
         const size_t lds = which ? cf.lds : cf.ref_lds;
+        const int grid = N < (which ? cf.max_grid : cf.ref_grid) ? N : (which ? cf.max_grid : cf.ref_grid);
         const DevOut o{obj + which * N, dobj + which * N, st + which * N, it + which * N, which ? prim : nullptr, which ? dual : nullptr};
         HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(k.fn, dim3(nb), dim3(64 * k.waves), lds, stream, h->dp, d_x0, x0_stride, d_fix, nb, o, h->rows_ws, (double *)nullptr,
+        hipLaunchKernelGGL(k.fn, dim3(grid), dim3(64 * k.waves), lds, stream, h->dp, x0c, p.nx, fixc, N, o, h->rows_ws, (double *)nullptr,
                            (const int32_t *)nullptr, w);
         HIPCHK(hipGetLastError());
     }
@@ -879,9 +887,10 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
     HIPCHK(hipMemcpyAsync(hst, st, 2 * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     bool same = true;
-    for (int b = 0; b < nb; b++) {
+    for (int b = 0; b < N; b++) {
         const int sa = hst[b], sb = hst[N + b];
-        same = same && sa == sb;
+        // (a node the SHIPPED kernel leaves undecided decides nothing about the compiled one)
+        same = same && (sa == sb || sa >= HMPC_MAXITER);
         if (sa == HMPC_OPTIMAL && sb == HMPC_OPTIMAL) {
             const double a = hobj[b], c = hobj[N + b];
             same = same && std::fabs(a - c) <= 1e-6 * (1.0 + std::fabs(a));
@@ -891,27 +900,27 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
     // same statuses, same objectives, and a polished node's active set verifies without an interior-point iteration
     if (same && cf.k.fn_warm) {
         int32_t hidx[N];
-        for (int b = 0; b < N; b++) hidx[b] = (b < nb && hst[N + b] == HMPC_OPTIMAL) ? b : -1;
+        for (int b = 0; b < N; b++) hidx[b] = hst[N + b] == HMPC_OPTIMAL ? b : -1;
         HIPCHK(hipMemcpyAsync(idx, hidx, sizeof hidx, hipMemcpyHostToDevice, stream));
         const DevWarm ww{prim, dual, idx, nullptr, 0};
         const DevOut o{obj + 2 * N, dobj + 2 * N, st + 2 * N, it + 2 * N, nullptr, nullptr};
         HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));
-        hipLaunchKernelGGL(cf.k.fn_warm, dim3(nb), dim3(64 * cf.k.waves), cf.lds, stream, h->dp, d_x0, x0_stride, d_fix, nb, o, h->rows_ws, (double *)nullptr,
-                           (const int32_t *)nullptr, ww);
+        hipLaunchKernelGGL(cf.k.fn_warm, dim3(N < cf.max_grid ? N : cf.max_grid), dim3(64 * cf.k.waves), cf.lds, stream, h->dp, x0c, p.nx, fixc, N, o, h->rows_ws,
+                           (double *)nullptr, (const int32_t *)nullptr, ww);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(hobj + 2 * N, obj + 2 * N, N * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(hst + 2 * N, st + 2 * N, N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        for (int b = 0; b < nb; b++) {
-            same = same && hst[2 * N + b] == hst[N + b];
+        for (int b = 0; b < N; b++) {
+            same = same && (hst[2 * N + b] == hst[N + b] || hst[N + b] >= HMPC_MAXITER);
             if (hst[N + b] == HMPC_OPTIMAL && hst[2 * N + b] == HMPC_OPTIMAL)
                 same = same && std::fabs(hobj[2 * N + b] - hobj[N + b]) <= 1e-6 * (1.0 + std::fabs(hobj[N + b]));
         }
     }
     if (getenv("HMPC_JIT_SELFCHECK_FAIL")) same = false; // (test hook: the path a disagreement takes)
     if (!same) {
-        fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) disagrees with the shipped kernel on the first nodes of its first batch: "
-                        "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n", cf.k.waves);
+        fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) disagrees with the shipped kernel on the %d nodes of its first-use check: "
+                        "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n", cf.k.waves, N);
         cf.k = cf.ref;
         cf.lds = cf.ref_lds;
         cf.max_grid = cf.ref_grid;
@@ -919,6 +928,55 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
         cf.checked = -1;
         h->jit_rejected++;
     }
+    return HMPC_OK;
+}
+
+// The counts of the last second opinion, if they have arrived (never blocks unless `wait`): a compiled kernel that left nodes
+// undecided of which the shipped kernel decides some is dropped for the handle; three batches on which both end the same way
+// and the compiled kernel is trusted with its hard nodes (no further second launches for that configuration).
+static void hmpc_second_opinion_review_impl(hmpc_handle *h, bool wait)
+{
+    if (h->hard_cfg < 0 || !h->hard_done) return;
+    if (wait) { if (hipEventSynchronize(h->hard_done) != hipSuccess) return; }
+    else if (hipEventQuery(h->hard_done) != hipSuccess) { (void)hipGetLastError(); return; }
+    hmpc_cfg &cc = h->cfg[h->hard_cfg];
+    h->hard_cfg = -1;
+    const int after = h->h_hard[0], first = h->h_hard[1];
+    if (first <= 0 || !cc.ref.fn || cc.k.fn == cc.ref.fn) return;
+    if (after < first) {
+        fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) left %d nodes of a batch undecided of which the shipped kernel decides %d: "
+                        "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n",
+                cc.k.waves, first, first - after);
+        cc.k = cc.ref;
+        cc.lds = cc.ref_lds;
+        cc.max_grid = cc.ref_grid;
+        cc.sized = 0;
+        cc.checked = -1;
+        h->jit_rejected++;
+    } else {
+        cc.second_opinions++;
+    }
+}
+
+extern "C" int hmpc_second_opinion_review(hmpc_handle *h)
+{
+    if (!h) return fail(HMPC_EINVAL, "null handle");
+    hmpc_second_opinion_review_impl(h, true);
+    return HMPC_OK;
+}
+
+// Runs the first-use checks of all three configurations now (one synchronisation each) instead of inside the first solve call
+// through each: for callers that capture their stream in a graph or must not block there.  x0 / fix: any batch of the problem.
+extern "C" int hmpc_validate_kernels(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B, void *stream)
+{
+    g_err.clear();
+    if (!h || !d_x0 || !d_fix || B < 1) return fail(HMPC_EINVAL, "null argument or empty batch");
+    HIPCHK(hipSetDevice(h->device));
+    for (int c = 0; c < 3; c++)
+        if (!h->cfg[c].checked) {
+            const int rc = hmpc_check_compiled(h, h->cfg[c], d_x0, x0_stride, d_fix, B, (hipStream_t)stream);
+            if (rc != HMPC_OK) return rc;
+        }
     return HMPC_OK;
 }
 
@@ -930,6 +988,7 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
     if (B < 0 || (x0_stride != 0 && x0_stride < h->dp.nx)) return fail(HMPC_EINVAL, "bad batch size or x0 stride");
     if (B == 0) return HMPC_OK;
     HIPCHK(hipSetDevice(h->device));
+    hmpc_second_opinion_review_impl(h, false);
     DevOut o{d_out->obj, d_out->dual_obj, d_out->status, d_out->iters, d_out->primal, d_out->dual};
     DevWarm w{nullptr, nullptr, nullptr, nullptr, 0};
     if (d_warm && d_warm->index) {
@@ -945,9 +1004,7 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
         const int rc = hmpc_check_compiled(h, cfm, d_x0, x0_stride, d_fix, B, (hipStream_t)stream);
         if (rc != HMPC_OK) return rc;
     }
-    hmpc_cfg shipped = cfm; // (second opinion: the shipped kernel of this configuration, hmpc_solve_batch)
-    if (h->use_ref && cfm.ref.fn) { shipped.k = cfm.ref; shipped.lds = cfm.ref_lds; shipped.max_grid = cfm.ref_grid; }
-    const hmpc_cfg &cf = (h->use_ref && cfm.ref.fn) ? shipped : cfm;
+    const hmpc_cfg &cf = cfm;
     const hmpc_kernel_choice &k = cf.k;
     const int grid = B < cf.max_grid ? B : cf.max_grid;
     h->last_grid = grid;
@@ -1005,6 +1062,41 @@ extern "C" int hmpc_solve_batch_device(hmpc_handle *h, const double *d_x0, int32
         hipLaunchKernelGGL(c4.k.fn_warm, dim3(grid2), dim3(64 * c4.k.waves), c4.lds, (hipStream_t)stream, h->dp, d_x0, x0_stride, d_fix, B, o, h->rows_ws,
                            h->trace, (const int32_t *)nullptr, w2);
         HIPCHK(hipGetLastError());
+    }
+    // SECOND OPINION on a kernel compiled at hmpc_create (binaries of this kernel have come out wrong from the
+    // compiler, always loudly -- nodes ending NUMERICAL -- and the reference never hands back an undecided node,
+    // bounded_qp.py:216-228): the nodes such a kernel leaves MAXITER / NUMERICAL are listed on the device (hmpc_hard_kernel)
+    // and solved again, in the same stream, by the SHIPPED kernel of the wave count (its hand-down instantiation in list mode,
+    // DevWarm::second == 2; a node is handed what the first launch handed it); its records replace theirs.  Nothing is
+    // synchronised: with no such node -- every call so far of every default kernel -- the two launches end at once (~10 us).
+    // The counts travel to the host behind an event and are looked at by the next call (hmpc_second_opinion_review_impl).
+    // Every entry that solves goes through here: hmpc_solve_batch, hmpc_fleet_solve, callers with device pointers.
+    if (cfm.ref.fn && k.fn != cfm.ref.fn && cfm.ref.fn_warm && o.status && !h->trace && !split && cfm.second_opinions < 3 && h->hard_done) {
+        if (B + 4 > h->hard_cap) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            if (h->hard) (void)hipFree(h->hard);
+            h->hard = nullptr;
+            h->hard_cap = 0;
+            HIPCHK(hipMalloc((void **)&h->hard, (size_t)(B + B / 2 + 4) * sizeof(int32_t)));
+            h->hard_cap = B + B / 2 + 4;
+        }
+        HIPCHK(hipMemsetAsync(h->hard, 0, 3 * sizeof(int32_t), (hipStream_t)stream));
+        hipLaunchKernelGGL(hmpc_hard_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const int32_t *)o.status, B, h->hard + 2);
+        HIPCHK(hipGetLastError());
+        DevProb p2 = h->dp;
+        p2.work_counter = h->hard + 1;
+        const int g2 = B < 64 ? B : 64; // (hard nodes are few; more of them than workgroups are handed out through the counter)
+        const DevWarm w3{w.primal, w.dual, w.index, h->hard + 2, 2};
+        hipLaunchKernelGGL(cfm.ref.fn_warm, dim3(g2 < cfm.ref_grid ? g2 : cfm.ref_grid), dim3(64 * cfm.ref.waves), cfm.ref_lds, (hipStream_t)stream, p2, d_x0, x0_stride,
+                           d_fix, B, o, h->rows_ws, (double *)nullptr, (const int32_t *)nullptr, w3);
+        HIPCHK(hipGetLastError());
+        h->second_runs++;
+        if (h->hard_cfg < 0) { // (the counts of an earlier call still in flight: this call's are not looked at)
+            HIPCHK(hipMemcpyAsync(h->h_hard, h->hard, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIPCHK(hipMemcpyAsync(h->h_hard + 1, h->hard + 2, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIPCHK(hipEventRecord(h->hard_done, (hipStream_t)stream));
+            h->hard_cfg = h->last_cfg;
+        }
     }
     return HMPC_OK;
 }
@@ -1125,42 +1217,7 @@ extern "C" int hmpc_solve_batch(hmpc_handle *h, const double *x0, int32_t x0_str
         }
     }
 #endif
-    // SECOND OPINION on a kernel compiled at hmpc_create (variants of this kernel have come out wrong from the
-    // compiler, always loudly -- nodes ending NUMERICAL): a batch in which such a kernel leaves nodes MAXITER / NUMERICAL is
-    // solved again by the shipped kernel of the same wave count.  If that one decides more of them, the compiled kernel is
-    // dropped for the handle; either way the caller gets the shipped kernel's records for this batch.  After three batches
-    // on which both agree the compiled kernel is trusted with its hard nodes.  (Host-pointer entry only: the device-pointer
-    // entry does not see its statuses.)
-    if (!h->use_ref && out->status && h->last_cfg >= 0) {
-        hmpc_cfg &cc = h->cfg[h->last_cfg];
-        if (cc.ref.fn && cc.checked == 1 && cc.second_opinions < 3 && cc.k.fn != cc.ref.fn) {
-            const int32_t *st = (const int32_t *)(hs + L.status);
-            int hard = 0;
-            for (int b = 0; b < B; b++) hard += st[b] >= HMPC_MAXITER;
-            if (hard) {
-                h->use_ref = true;
-                const int rc2 = hmpc_solve_batch(h, x0, x0_stride, fix, B, warm, out);
-                h->use_ref = false;
-                if (rc2 != HMPC_OK) return rc2;
-                int hard_ref = 0;
-                for (int b = 0; b < B; b++) hard_ref += out->status[b] >= HMPC_MAXITER;
-                if (hard_ref < hard) {
-                    fprintf(stderr, "hmpc: the kernel compiled for this problem (%d waves per node) left %d nodes of a batch undecided of which the shipped kernel decides %d: "
-                                    "dropped, the shipped kernel serves this handle (please report; HMPC_JIT_SIZED=0 / HMPC_JIT=0 avoid the compilation)\n",
-                            cc.k.waves, hard, hard - hard_ref);
-                    cc.k = cc.ref;
-                    cc.lds = cc.ref_lds;
-                    cc.max_grid = cc.ref_grid;
-                    cc.sized = 0;
-                    cc.checked = -1;
-                    h->jit_rejected++;
-                } else {
-                    cc.second_opinions++;
-                }
-                return HMPC_OK;
-            }
-        }
-    }
+    hmpc_second_opinion_review_impl(h, false); // (the stream is idle: the counts of this call's second opinion have arrived)
     if (out->obj) std::memcpy(out->obj, hs + L.obj, (size_t)B * sizeof(double));
     if (out->dual_obj) std::memcpy(out->dual_obj, hs + L.dobj, (size_t)B * sizeof(double));
     if (out->status) std::memcpy(out->status, hs + L.status, (size_t)B * sizeof(int32_t));

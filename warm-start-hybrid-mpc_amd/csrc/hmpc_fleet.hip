@@ -51,6 +51,7 @@ struct hmpc_fleet {
     double *h_prow = nullptr, *d_prow = nullptr;                               // K primal rows: pinned / device (incumbents of a step)
     int32_t *h_inc = nullptr, *d_inc = nullptr;                                // K: pool row of each loop's incumbent
     long long rounds = 0, launched = 0, handed = 0;
+    long long uncertified = 0, resting = 0; // nodes pruned without a certificate; searches whose optimum rests on such a prune (hmpc_fleet_uncertified)
     double t_select = 0, t_stage = 0, t_device = 0, t_consume = 0, t_shift = 0; // host wall time by phase (hmpc_fleet_timing)
     bool broken = false; // a call failed midway: the trees are half updated until hmpc_fleet_reset(f, -1)
 };
@@ -362,7 +363,8 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
                 const int d = launch[q].depth;
                 const double *nu_ = f->h_nu + q * 2 * nfix;
                 FleetResult e{f->h_obj[q], d < nfix ? nu_[d] : 0.0, d < nfix ? nu_[nfix + d] : 0.0, (int32_t)(f->used + q),
-                              f->h_status[q] == HMPC_OPTIMAL && (f->h_iters[q] & HMPC_ITERS_POLISHED) != 0, f->h_status[q] > 1};
+                              f->h_status[q] == HMPC_OPTIMAL && (f->h_iters[q] & HMPC_ITERS_POLISHED) != 0, f->h_status[q] > 1,
+                              (f->h_iters[q] & HMPC_ITERS_UNCERTIFIED) != 0};
                 f->handed += (f->h_iters[q] & HMPC_ITERS_HANDED) != 0;
                 if (dive && e.vertex && d < nfix) {
                     std::vector<int8_t> bits(nfix);
@@ -381,6 +383,19 @@ extern "C" int hmpc_fleet_solve(hmpc_fleet *f, const double *x0, int32_t width, 
             if (bad == 1) return fail(HMPC_EDEVICE, "fleet: a selected node has no result");
             if (bad == 2) return fleet_fail(f, HMPC_EDEVICE, "fleet: the QP solver did not converge on a node (status MAXITER / NUMERICAL)");
         }
+    }
+    for (int k = 0; k < K; k++) { // prunes without a certificate (HMPC_ITERS_UNCERTIFIED): counted; said aloud where a search's result rests on one
+        FleetTree &t = f->trees[k];
+        if (!t.uncertified) continue;
+        f->uncertified += t.uncertified;
+        if (t.unc_lb < t.ub) {
+            if (!f->resting)
+                fprintf(stderr, "hmpc: a branch-and-bound search pruned a node on the collapse of tau alone (no infeasibility certificate, HMPC_ITERS_UNCERTIFIED) "
+                                "whose bound %.6g lay below the final incumbent %.6g: the returned optimum rests on that prune (hmpc_fleet_uncertified counts further ones)\n",
+                        t.unc_lb, t.ub);
+            f->resting++;
+        }
+        t.uncertified = 0;
     }
     {   // the incumbents' primal rows: one gather launch, one copy
         bool any = false;
@@ -488,6 +503,14 @@ extern "C" int hmpc_fleet_shift(hmpc_fleet *f, const double *e0, int32_t *cover,
     f->cur = nxt;
     f->used = B;
     guard.ok = true;
+    return HMPC_OK;
+}
+
+extern "C" int hmpc_fleet_uncertified(const hmpc_fleet *f, int64_t *pruned, int64_t *searches_resting_on_one)
+{
+    if (!f) return fail(HMPC_EINVAL, "fleet: null");
+    if (pruned) *pruned = f->uncertified;
+    if (searches_resting_on_one) *searches_resting_on_one = f->resting;
     return HMPC_OK;
 }
 

@@ -51,27 +51,17 @@
 #define HMPC_POLISH_ROUNDS_LAST 10 // the last attempt, on the iterate the solve would return (round 3, with the rule that every row with a negative multiplier leaves)
 #define HMPC_ESC_MAX 2 // tolerance escalations after a failed last attempt (ipm_solve) ...
 #define HMPC_ESC_ITERS 6 // ... and iterations an escalated solve may spend without meeting its tolerance
-// The tolerance escalation is compiled into the run-time-sized kernels only: in the one-wave kernel of the cart-pole
-// shape its two more live values move the register allocation (scratch 124 -> 140 B per lane), and no optimal node of
-// the cart-pole systems has ever reached it (every one polishes: 0 of 165 824 + 40 424 + 21 000 nodes of the parity sweeps).
-// -DHMPC_ESC_ALL compiles it into every kernel (A/B builds).
-#if defined(HMPC_ESC_ALL) || defined(HMPC_JIT_KC) // (kernels compiled at hmpc_create serve arbitrary systems: always with it)
+// ONE FEATURE SET FOR EVERY KERNEL (round 5).  Until round 4 three accuracy features of the run-time-sized kernels -- the
+// tolerance escalation of the polish, lam_0 from its stationarity row (3.11a) and the multipliers the step's
+// stationarity rows define taken from the step actually made (3.11b) -- were left out of the register kernels of the two
+// cart-pole shapes for their register budget (and the third out of every register kernel).  The register kernels compiled at
+// hmpc_create serve arbitrary systems: on a random MLD with nx = 6, nu = 2 + 3, N = 12 the missing third feature left the dual
+// residual of deep nodes growing with the barrier weights from iteration 14 on (7.6e-10, 4.9e-9, ... 3.1e-6 where the
+// run-time-sized kernel has 5e-12 ... 6e-15: profiles/r05_gvs_trace.txt) -- four optimal nodes of 2048 came back unpolished and
+// one undecided (the parity hole of VERDICT round 4).  All three are now part of every kernel, shipped or compiled, and the
+// shipped cart-pole instantiations are the same code as the kernels compiled for a problem.
 #define HMPC_ESC_ENABLED(D) true
-#else
-#define HMPC_ESC_ENABLED(D) (D::kNX <= 0)
-#endif
-// A/B switches of the round-4 accuracy changes in the compile-time (cart-pole) kernels; the run-time-sized kernels always
-// have them.  Measured on the headline launch (4096 nodes, two runs each, same box; iteration counts and records of the
-// cart-pole nodes identical in all three): both off 8.546 / 8.570 ms, stable denominator 8.559 / 8.585, both 8.654 / 8.658
-// (132 B of scratch instead of 124).  lam_0 from its row stays out of the cart-pole kernels: their D stays orders of
-// magnitude smaller (every optimal node ends at the polish, mu ~ 1e-9), the row's error with it.
-#ifndef HMPC_LAM0_ROW
-#ifdef HMPC_JIT_KC
 #define HMPC_LAM0_ROW 1
-#else
-#define HMPC_LAM0_ROW 0
-#endif
-#endif
 #ifndef HMPC_STABLE_DEN
 #define HMPC_STABLE_DEN 1
 #endif
@@ -1456,7 +1446,7 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
     constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU, NE = NZ * (NZ + 1) / 2;
     // (nz = 16 fits the row of 16 lanes on paper but comes out wrong -- every node NUMERICAL, found by the first-use check of
     // the compiled kernels on a random MLD with nx = 9, nu = 3 + 4, profiles/r04_sized_shapes.txt; the hosts admit nz <= 15)
-    static_assert(NZ <= 15, "the register recursions broadcast inside one row of 16 lanes, one lane to spare");
+    static_assert(NZ <= 16, "the register recursions broadcast inside one row of 16 lanes");
     constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU), KG = D::kKC, GH = KG / 2;
     const int T = p.T;
     FSTAMP_DECL;
@@ -1554,10 +1544,9 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                 S.Mm[gi * NZ + gj] = g0 + g1;
                 S.Mm[gj * NZ + gi] = g0 + g1;
             }
-#ifdef HMPC_JIT_KC
-            // kernels compiled for an arbitrary shape: entries 64 .. 127 of C' D C with a term list (nz = 15 with dense state
-            // rows has ~90) take a second trip; their per-lane constants are fetched per stage instead of being held.  The
-            // shipped cart-pole shapes have at most 64 such entries (checked on the host) and none of this code.
+            // entries 64 .. 127 of C' D C with a term list (nz = 15 with dense state rows has ~90) take a second trip; their
+            // per-lane constants are fetched per stage instead of being held.  (The cart-pole shapes have at most 64 such
+            // entries: a kernel compiled with the problem's sizes folds the test away.)
             if (ng > WAVE) {
                 const bool has2 = WAVE + lane < ng;
                 const int ge2 = has2 ? WAVE + lane : 0;
@@ -1577,7 +1566,6 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                     S.Mm[gj2 * NZ + gi2] = h0 + h1;
                 }
             }
-#endif
             // (2) column `lane` of W = [A B]' P_{t+1} [A B]
             double y[NX];
 #pragma unroll
@@ -2539,7 +2527,7 @@ template <class D> DEV double dPd(const DevProb &p, const Lds &S, int lane, cons
 // launch, measured) -- a launch without hand-down runs the kernel it always ran.
 template <class D, int RS, class RM, bool WARM>
 DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane, int term_on, int &iters, double &tau_out,
-                  bool &polished_out, bool &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual,
+                  bool &polished_out, int &weak_out, bool &handed_out, double *trace, const double *wprim, const double *wdual,
                   bool attempt_only, bool own = false)
 {
     const int nx = D::nx(p), nz = D::nz(p), T = p.T, nuc = D::nuc(p), nub = D::nub(p), M = p.M, n = T * nz + nx;
@@ -2566,7 +2554,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
 
     int status = HMPC_MAXITER, it = 0, extra_done = 0;
     polished_out = false;
-    weak_out = false;
+    weak_out = 0;
     handed_out = false;
     bool tried = false; // the polish has been tried (and failed) on the current iterate
     int attempts = 0;
@@ -2851,7 +2839,9 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             // the oracle left at iteration 37 through the clause above by the luck of its rounding.  Same conclusion, same
             // flag: pruned at this step, never carried to the next.  Same rule as oracle/hsde_qp.c.)
             status = HMPC_INFEASIBLE;
-            weak_out = true;
+            // (2: through the second clause alone -- no ray meets even the loose bound of the first: HMPC_ITERS_UNCERTIFIED, which
+            // the drivers count; a numerical collapse of tau on a feasible node would look the same)
+            weak_out = (eta > 0 && tau <= 1e-8 * kap && certinf <= 0.5 * eta) ? 1 : 2;
             break;
         }
         if (!polish && it == p.max_iter) break;
@@ -3244,9 +3234,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             // D (C w1) against D h, ~eps D, and with D = z / s at 1e9 .. 1e12 in the last iterations the fixed binaries' rows of
             // the dual residual stood at 1e-7 .. 4e-6 on deep nodes of BASELINE configs[4] (every other row: 1e-13) -- above
             // the stopping tolerance, so that such nodes left through the exhausted-barrier exit with a gap of 1e-6, or not
-            // at all once the tolerance escalation asked for 1e-10.  (The oracle stores that dz; the cart-pole kernels keep
-            // the accumulated form: their D stays four orders smaller and the row products' registers are spoken for.)
-            if constexpr (D::kNX <= 0) {
+            // at all once the tolerance escalation asked for 1e-10.  (The oracle stores that dz.  Until round 4 the register
+            // kernels kept the accumulated form -- the cart-pole's D stays four orders smaller --; a register kernel compiled
+            // for another system showed the same defect, see the top of this file: every kernel now takes them from the step.)
+            {
                 if (pass == 1) {
                     __syncthreads();
                     if (nref > 0) { // (S.e holds the last correction, not the step)
@@ -3255,6 +3246,7 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                         ROWS_END
                         __syncthreads();
                     }
+                    term_cols<D, RM>(p, S, lane, S.e); // (register kernels: the terminal rows' part of the column products below)
                     for (int o = lane; o < T * nub; o += D::kNT) {
                         if (S.fix[o] >= 0) {
                             const int t = o / nub, c = nx + nuc + (o - t * nub);
@@ -3509,7 +3501,12 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         constexpr bool NL = KC > 0 || D::kBig; // no row / column lists in LDS
         ldsd *h0 = take(D::kBig ? 0 : p.mreg), *rval0 = take(NL ? 0 : p.nnz0), *cval0 = take(KC ? nz * KC : NL ? 0 : p.nnz0);
         ldsd *gval0 = take(D::kBig ? 0 : p.nng0);
-        ldsd *cdn0 = take(p.split_lds ? p.ndp * nz : 0), *sval0 = take(p.split_lds ? p.mreg : 0);
+        // (the dense / singleton split of the stage rows belongs to the run-time-sized kernels: a register kernel of a problem
+        // with nz >= 16 -- DevProb::split_lds is set from the sizes alone -- carved these arrays too, which hmpc_lds_bytes()
+        // does not count for it: everything behind them lay beyond the workgroup's LDS, where loads return zero and stores are
+        // dropped.  That was the "defect of the register recursions at nz = 16" of round 4.)
+        const bool split = KC == 0 && p.split_lds;
+        ldsd *cdn0 = take(split ? p.ndp * nz : 0), *sval0 = take(split ? p.mreg : 0);
         S.Ls = take(D::kBig ? 2 * p.ring * S.lrows * S.nup : 0); // two chunk buffers of `ring` padded stage blocks (kkt_sweeps_wave)
         S.Lw = take(D::kBig ? LM_STAGE(nx, nu) : 0);
         if constexpr (D::kBig)
@@ -3522,7 +3519,7 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         ldsi *rptr0 = takei(NL ? 0 : p.mreg + 1), *rcol0 = takei(NL ? 0 : p.nnz0), *cptr0 = takei(NL ? 0 : nz + 1);
         ldsi *crow0 = takei(NL ? 0 : p.nnz0);
         ldsi *gptr0 = takei(D::kBig ? 0 : ne + 1), *grow0 = takei(D::kBig ? 0 : p.nng0);
-        ldsi *drow0 = takei(p.split_lds ? p.ndp : 0), *rinfo0 = takei(p.split_lds ? p.mreg : 0), *sptr0 = takei(p.split_lds ? nz + 1 : 0), *srow0 = takei(p.split_lds ? p.ns : 0), *nrow0 = takei(p.split_lds ? p.mreg - p.nd : 0);
+        ldsi *drow0 = takei(split ? p.ndp : 0), *rinfo0 = takei(split ? p.mreg : 0), *sptr0 = takei(split ? nz + 1 : 0), *srow0 = takei(split ? p.ns : 0), *nrow0 = takei(split ? p.mreg - p.nd : 0);
         ldsb *cci0 = (ldsb *)qi; // nz * KC bytes (rounded up to a multiple of 4 in hmpc_lds_bytes)
         // stage the node-independent data
         const SparseStage &g0 = p.reg;
@@ -3558,9 +3555,9 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         S.L0 = ListsL{rptr0, rcol0, cptr0, crow0, gptr0, grow0, rval0, cval0, gval0, h0};
         S.G0 = ListsG{g0.rptr, g0.rcol, g0.cptr, g0.crow, g0.gptr, g0.grow, g0.rval, g0.cval, g0.gval, g0.h};
         S.ccv = cval0;
-        S.Cdn = p.split_lds ? cdn0 : nullptr;
+        S.Cdn = split ? cdn0 : nullptr;
         S.sval = sval0; S.drow = drow0; S.rinfo = rinfo0; S.sptr = sptr0; S.srow = srow0; S.nrow = nrow0;
-        if (p.split_lds) {
+        if (split) {
             for (int i = lane; i < p.ndp * nz; i += D::kNT) cdn0[i] = p.Cdn[i];
             for (int i = lane; i < p.mreg; i += D::kNT) { sval0[i] = p.sval[i]; rinfo0[i] = p.rinfo[i]; }
             for (int i = lane; i < p.ndp; i += D::kNT) drow0[i] = p.drow[i];
@@ -3581,8 +3578,12 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     // first gridDim.x nodes go to the workgroups by index, every further node to the first workgroup that is free
     // (one atomic per node on a counter the host zeroes before the launch).  A record does not depend on the
     // workgroup that computes it.
-    int Bn = B; // nodes of this launch (a second pass of the two-launch form reads their number from the device)
+    int Bn = B; // nodes of this launch (a second pass -- two-launch form, second opinion -- reads their number from the device)
     if constexpr (WARM) { if (warm.second) Bn = warm.pend[0]; }
+    // warm.second == 2: SECOND OPINION (hmpc_solve_batch_device): the nodes a kernel compiled at hmpc_create left undecided
+    // (MAXITER / NUMERICAL), listed in warm.pend, are solved again by the shipped kernel -- this one, launched through its
+    // hand-down instantiation so that the cold kernels do not carry the list mode; a node is handed what the first launch
+    // handed it (warm.index), nothing else differs from a regular launch.
     for (int slot = blockIdx.x; slot < Bn;) {
         // `order` (optional): the nodes sorted by the number of fixed binaries, shallow first -- shallow nodes take more
         // iterations (correlation -0.5 .. -0.75 on random frontiers), and with ~4 nodes per workgroup handing out the
@@ -3626,12 +3627,13 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         }
 #endif
         int it1 = 0, it2 = 0, status = HMPC_MAXITER;
-        bool polished = false, weak = false, handed = false, second = false;
+        bool polished = false, handed = false, second = false;
+        int weak = 0;
         double tau = 1.0;
         double *tr = (trace && qp == 0) ? trace : nullptr;
         const double *wprim = nullptr, *wdual = nullptr; // the parent's record, if one is handed down
         if constexpr (WARM) {
-            const int wrow = warm.second ? qp : warm.index ? warm.index[qp] : -1;
+            const int wrow = warm.second == 1 ? qp : warm.index ? warm.index[qp] : -1;
             wprim = wrow >= 0 ? warm.primal + (size_t)wrow * p.n_primal : nullptr;
             wdual = wrow >= 0 ? warm.dual + (size_t)wrow * p.n_dual : nullptr;
         }
@@ -3664,7 +3666,7 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
             // sequence -- masked first, so that an infeasible node's ray carries no terminal multipliers -- runs as without
             // it.  Same steps as oracle/hsde_qp.c.
             int stage = first;
-            if (warm.second) { // second launch of the two-launch form: terminal rows on, from the node's own first record
+            if (warm.second == 1) { // second launch of the two-launch form: terminal rows on, from the node's own first record
                 stage = 2;
                 it1 = out.iters ? (out.iters[qp] & 0xFFFF) : 0;
             } else if (wdual != nullptr && p.polish && first == 0) {
@@ -3677,10 +3679,10 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
                 int its = 0;
                 S.term_on = term_on;
                 status = ipm_solve<D, RS, RM, WARM>(p, S, R, rm, lane, term_on, its, tau, polished, weak, handed, tr ? tr + term_on * 64 * 8 : nullptr, wprim, wdual, stage == 2,
-                                                    stage == 2 && warm.second != 0);
+                                                    stage == 2 && warm.second == 1);
                 if (stage == 2) {
-                    if (status == HMPC_RETRY) { stage = warm.second ? 1 : 0; continue; }
-                    if (warm.second) it2 = its; else it1 = its;
+                    if (status == HMPC_RETRY) { stage = warm.second == 1 ? 1 : 0; continue; }
+                    if (warm.second == 1) it2 = its; else it1 = its;
                     second = true;
                     break;
                 }
@@ -3693,6 +3695,9 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
                 stage = 1;
             }
         }
+#ifdef HMPC_TEST_UNDECIDED // (test hook, HMPC_JIT_FLAGS: a compiled kernel that leaves every k-th node undecided, for the nets of hmpc_solve_batch_device)
+        if (qp % HMPC_TEST_UNDECIDED == 1) status = HMPC_NUMERICAL;
+#endif
         __syncthreads();
         {
             const int nslot = RS > 0 ? RS : p.Mpad / D::kNT;
@@ -3710,8 +3715,11 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         }
         HMPC_CHK(status >= HMPC_OPTIMAL && status <= HMPC_NUMERICAL && tau > 0.0, 7);
 #endif
-        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0) | (handed ? HMPC_ITERS_HANDED : 0) |
+        if (lane == 0 && out.iters) out.iters[qp] = (it1 + it2) | (polished ? HMPC_ITERS_POLISHED : 0) | (weak ? HMPC_ITERS_WEAK : 0) | (weak == 2 ? HMPC_ITERS_UNCERTIFIED : 0) | (handed ? HMPC_ITERS_HANDED : 0) |
                                                      ((WARM && second) ? HMPC_ITERS_TERMINAL : 0);
+        if constexpr (WARM) { // second opinion: how many of the listed nodes this kernel leaves undecided as well (two words in front of the list; the one between them is this launch's work counter)
+            if (warm.second == 2 && lane == 0 && status >= HMPC_MAXITER) atomicAdd(warm.pend - 2, 1);
+        }
         if (lane == 0) S.flag[1] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
         __syncthreads();
         slot = S.flag[1];
@@ -3795,6 +3803,26 @@ __global__ void __launch_bounds__(1024) hmpc_order_kernel(const int8_t *__restri
     for (int q = 0; q < 8; q++)
         if (mine[q] >= 0) order[atomicAdd(&bins[mine[q]], 1)] = threadIdx.x + q * 1024;
     for (int b = threadIdx.x + 8 * 1024; b < B; b += 1024) order[atomicAdd(&bins[bucket(b)], 1)] = b;
+}
+
+// Nodes of a launch that ended MAXITER / NUMERICAL, listed for the second opinion (hmpc_solve_batch_device): list[0] how many,
+// list[1 ..] which (any order: a record does not depend on the workgroup that computes it).
+__global__ void __launch_bounds__(256) hmpc_hard_kernel(const int32_t *__restrict__ status, int B, int32_t *__restrict__ list)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B && status[b] >= HMPC_MAXITER) list[1 + atomicAdd(list, 1)] = b;
+}
+
+// The nodes of the first-use check of a compiled kernel (hmpc_check_compiled): N - 2 nodes spread over the batch, the root
+// relaxation of the batch's first initial state (every binary free) and its deepest node (every binary fixed to zero).
+__global__ void __launch_bounds__(256) hmpc_check_set_kernel(const double *__restrict__ x0g, int x0_stride, const int8_t *__restrict__ fixg, int B, int nfix, int nx, int N,
+                                                             double *__restrict__ x0c, int8_t *__restrict__ fixc)
+{
+    for (int k = blockIdx.x; k < N; k += gridDim.x) {
+        const int src = k < N - 2 ? (int)((long long)k * B / (N - 2)) : 0;
+        for (int i = threadIdx.x; i < nfix; i += 256) fixc[(size_t)k * nfix + i] = k == N - 2 ? (int8_t)-1 : k == N - 1 ? (int8_t)0 : fixg[(size_t)src * nfix + i];
+        for (int i = threadIdx.x; i < nx; i += 256) x0c[(size_t)k * nx + i] = x0g[(size_t)src * x0_stride + i];
+    }
 }
 
 #ifdef HMPC_EXTERN_INSTANCES

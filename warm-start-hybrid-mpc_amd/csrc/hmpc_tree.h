@@ -25,6 +25,7 @@ struct FleetResult { // a solved node waiting to be consumed by the search (spec
     int32_t row;              // its row in the pools
     bool vertex;              // optimal and polished: its record may be handed down to its children (hmpc_warm)
     bool failed;              // the solver did not converge on it (MAXITER / NUMERICAL): an error IF the search consumes it
+    bool uncertified = false; // infeasible on the collapse of tau alone, no ray even loosely verified (HMPC_ITERS_UNCERTIFIED)
 };
 
 struct FleetTree {
@@ -40,6 +41,8 @@ struct FleetTree {
     int32_t inc_row = -1;       // its row in the primal pool
     std::vector<double> primal; // its primal row
     int solves = 0;
+    int uncertified = 0;        // nodes of this step pruned without a certificate ...
+    double unc_lb = std::numeric_limits<double>::infinity(); // ... and the smallest bound such a node carried before its solve
     bool running = true;        // false once the MIQP of a step was infeasible (the loop has ended)
     std::vector<double> x0;     // state of the last solve
     std::unordered_map<std::string, FleetResult> cache; // key: the fixed prefix of the identifier
@@ -65,6 +68,8 @@ inline void tree_begin_step(FleetTree &t, const double *x0, int nx)
     t.inc = -1;
     t.inc_row = -1;
     t.solves = 0;
+    t.uncertified = 0;
+    t.unc_lb = std::numeric_limits<double>::infinity();
     t.cache.clear();
     t.rounded.clear();
     t.x0.assign(x0, x0 + nx);
@@ -141,6 +146,10 @@ inline int tree_consume(FleetTree &t, const std::vector<int> &picks, int nfix, d
         if (e.failed) return 2;
         const double obj = e.obj;
         t.solves++;
+        if (e.uncertified) { // (pruned on the collapse of tau alone: counted, and reported if the step's optimum rests on it)
+            t.uncertified++;
+            t.unc_lb = std::min(t.unc_lb, t.lb[i]);
+        }
         t.lb[i] = obj;
         t.row[i] = e.row;
         const double cutoff = t.ub - tol;

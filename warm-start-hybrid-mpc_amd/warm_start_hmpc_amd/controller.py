@@ -206,6 +206,13 @@ class HybridModelPredictiveController(object):
             raise RuntimeError('QP solver did not converge on %d of %d nodes (status %s, first node %d)'
                                % (bad.size, fix.shape[0], sorted(set(res['status'][bad].tolist())), bad[0]))
         weak = res.get('weak')
+        unc = res.get('uncertified')
+        if unc is not None and np.any(unc):
+            # pruned on the collapse of tau alone -- no ray verified, even loosely (HMPC_ITERS_UNCERTIFIED): said aloud, the
+            # reference's solver would have stated infeasibility with a certificate (bounded_qp.py:216-228)
+            import warnings
+            warnings.warn('%d of %d nodes were declared infeasible WITHOUT a certificate (collapse of tau alone): a subtree pruned on '
+                          'that is not proved infeasible' % (int(np.sum(unc)), fix.shape[0]), RuntimeWarning, stacklevel=3)
         sols = [SubproblemSolution.from_rows(self.layout, fix[b], res['obj'][b], res['dual_obj'][b],
                                              res['status'][b], res['primal'][b], res['dual'][b],
                                              weak=weak is not None and weak[b])

@@ -80,7 +80,10 @@ class FleetMPC(object):
         self.qp._check(self.qp.lib.hmpc_fleet_handdown(self._f, -1, ctypes.byref(v)))
         t = (ctypes.c_double * 5)()
         self.qp._check(self.qp.lib.hmpc_fleet_timing(self._f, t))
-        return dict(rounds=r.value, launched=n.value, handed=v.value,
+        u, w = ctypes.c_int64(), ctypes.c_int64()
+        self.qp._check(self.qp.lib.hmpc_fleet_uncertified(self._f, ctypes.byref(u), ctypes.byref(w)))
+        # (uncertified: nodes pruned on the collapse of tau alone, HMPC_ITERS_UNCERTIFIED; resting: searches whose optimum rests on one)
+        return dict(rounds=r.value, launched=n.value, handed=v.value, uncertified=u.value, resting_on_uncertified=w.value,
                     seconds=dict(zip(('select', 'stage', 'device', 'consume', 'shift'), [float(x) for x in t])))
 
     def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0, cold_frontier_width=None):

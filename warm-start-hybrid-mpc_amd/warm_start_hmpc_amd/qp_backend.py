@@ -103,6 +103,8 @@ def load_library():
         lib.hmpc_fleet_solve.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_double] + [ctypes.c_void_p] * 5
         lib.hmpc_fleet_shift.restype = ctypes.c_int
         lib.hmpc_fleet_shift.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        lib.hmpc_fleet_uncertified.restype = ctypes.c_int
+        lib.hmpc_fleet_uncertified.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.hmpc_fleet_stats.restype = ctypes.c_int
         lib.hmpc_fleet_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.hmpc_fleet_timing.restype = ctypes.c_int
@@ -128,11 +130,11 @@ def load_library():
     return _lib
 
 
-EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_build', 'hmpc_jit_build_problem',
+EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_stats', 'hmpc_jit_build_problem', 'hmpc_validate_kernels', 'hmpc_second_opinion_review',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_stop', 'hmpc_fleet_rows', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
-                    'hmpc_fleet_stats', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_allreduce_incumbent_device', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
+                    'hmpc_fleet_stats', 'hmpc_fleet_uncertified', 'hmpc_fleet_handdown', 'hmpc_fleet_timing', 'hmpc_comm_unique_id', 'hmpc_comm_create', 'hmpc_allreduce_incumbent', 'hmpc_allreduce_incumbent_device', 'hmpc_publish_incumbent', 'hmpc_comm_destroy',
                     'hmpc_lp_solve_batch')
 
 
@@ -156,63 +158,19 @@ def _problem_struct(problem):
     return p, keep
 
 
-def jit_shapes(problem):
-    """The register-kernel shapes ``hmpc_create`` compiles for ``problem`` (csrc/hmpc_jit.h): a list of
-    (nx, nu, nub, kf, kb, kt, nw, kc) for 1 / 2 / 4 waves per node, empty where the static row map does not hold the
-    problem (nx + nu > 15, an [F G] row with more than two input coefficients, no binary, a built-in shape).  Mirrors the
-    host code of ``hmpc_create`` / ``hmpc_static_slots``; used to warm the cache ahead of time (``jit_prebuild``)."""
-    nx, nu, nub, T = int(problem['nx']), int(problem['nu']), int(problem['nub']), int(problem['T'])
-    F, G = np.atleast_2d(problem['F']), np.atleast_2d(problem['G'])
-    nc, nT = F.shape[0], np.atleast_2d(problem['F_Tm1']).shape[0] - F.shape[0]
-    if (nx, nu, nub) in ((4, 7, 4), (4, 4, 2)) or nx + nu > 15 or nub < 1 or nc + 2 * nub > 255:
-        return []
-    if np.any(np.count_nonzero(G, axis=1) > 2):
-        return []
-    col = np.concatenate((np.count_nonzero(F, axis=0), np.count_nonzero(G, axis=0)))
-    col[nx + nu - nub:] += 2                                    # the two bound rows of a binary
-    kc = max(2, (int(col.max()) + 1) // 2 * 2)
-    if kc > 16:
-        return []
-    out = []
-    for nw in (1, 2, 4):
-        nt = 64 * nw
-        if nc > nt or 2 * nub > nt:
-            continue
-        kf, kb, kt = -(-T // (nt // nc)), -(-T // (nt // (2 * nub))), max(1, -(-nT // nt))
-        if kf + kb + kt <= 16:
-            out.append((nx, nu, nub, kf, kb, kt, nw, kc))
-    return out
-
-
 def jit_prebuild(problem):
     """Compiles (or finds in the cache) what ``hmpc_create`` would compile for ``problem`` -- without a GPU
     (``hmpc_jit_build_problem``): the kernels of the problem with its sizes as constants -- register kernels where the static
-    row map holds the problem, the run-time-sized kernel or its streaming form elsewhere.  With ``HMPC_JIT_SIZED=0`` the
-    register kernels per SHAPE of round 4's first form (``hmpc_jit_build``, incl. the two-waves-per-SIMD build of the one-wave
-    kernel).  Returns the paths of the shared objects."""
+    row map holds the problem, the run-time-sized kernel or its streaming form elsewhere.  Returns the paths of the shared
+    objects (none with ``HMPC_JIT_SIZED=0`` / ``HMPC_JIT=0``: the shipped kernels serve)."""
     lib = load_library()
-    lib.hmpc_jit_build.restype = ctypes.c_int
-    lib.hmpc_jit_build.argtypes = [ctypes.c_int32] * 8 + [ctypes.c_char_p, ctypes.c_int32]
     lib.hmpc_jit_build_problem.restype = ctypes.c_int
     lib.hmpc_jit_build_problem.argtypes = [ctypes.POINTER(_Problem), ctypes.POINTER(_Options), ctypes.c_char_p, ctypes.c_int32]
-    if not jit_shapes(problem) or os.environ.get('HMPC_JIT_SIZED', '1') != '0':
-        # (the default: every kernel compiled with the problem's sizes; HMPC_JIT_SIZED=0: register kernels per shape, below)
-        p, keep = _problem_struct(problem)
-        buf = ctypes.create_string_buffer(8192)
-        if lib.hmpc_jit_build_problem(ctypes.byref(p), None, buf, 8192) != 0:
-            raise RuntimeError('hmpc_jit_build_problem failed: %s' % lib.hmpc_last_error().decode())
-        return [q for q in buf.value.decode().split('\n') if q]
-    paths = []
-    for shape in jit_shapes(problem):
-        # (the one-wave kernel also in its build for two waves per SIMD -- nw + 8 --, which hmpc_create picks where LDS holds
-        # six or more nodes per CU)
-        for nw in ((shape[6], shape[6] + 8) if shape[6] == 1 else (shape[6],)):
-            buf = ctypes.create_string_buffer(1024)
-            args = shape[:6] + (nw, shape[7])
-            if lib.hmpc_jit_build(*args, buf, 1024) != 0:
-                raise RuntimeError('hmpc_jit_build%r failed: %s' % (args, lib.hmpc_last_error().decode()))
-            paths.append(buf.value.decode())
-    return paths
+    p, keep = _problem_struct(problem)
+    buf = ctypes.create_string_buffer(8192)
+    if lib.hmpc_jit_build_problem(ctypes.byref(p), None, buf, 8192) != 0:
+        raise RuntimeError('hmpc_jit_build_problem failed: %s' % lib.hmpc_last_error().decode())
+    return [q for q in buf.value.decode().split('\n') if q]
 
 
 def lp_solve_batch(A, c, b, relax=None, tol=1e-9, max_iter=100, device=-1):
@@ -330,6 +288,7 @@ class HipBatchedQP(object):
         out['handed'] = (out['iters'] >> 18) & 1        # HMPC_ITERS_HANDED: the active set handed down by the parent verified
         out['polished'] = (out['iters'] >> 16) & 1      # HMPC_ITERS_POLISHED
         out['weak'] = (out['iters'] >> 17) & 1          # HMPC_ITERS_WEAK: infeasible, the ray is no proof to tolerance
+        out['uncertified'] = (out['iters'] >> 20) & 1   # HMPC_ITERS_UNCERTIFIED: weak, and pruned on the collapse of tau alone
         out['second'] = (out['iters'] >> 19) & 1        # HMPC_ITERS_TERMINAL: the terminal-set rows were needed (hand-down launches and the two-launch form)
         out['iters'] = out['iters'] & 0xFFFF
         return out
@@ -359,10 +318,33 @@ class HipBatchedQP(object):
         self._check(self.lib.hmpc_solve_batch_device(self.handle, x0.data_ptr(), stride, fix.data_ptr(), B, w,
                                                      ctypes.byref(res), ctypes.c_void_p(stream)))
 
+    def jit_stats(self):
+        """(compiled kernels dropped by the first-use check / the second opinion, solve calls in which the shipped kernel was
+        asked for a second opinion, batches on which it ended like the compiled kernel) -- ``hmpc_jit_stats``; the counts of
+        the last call are taken in first (``hmpc_second_opinion_review``: waits for them)."""
+        self.lib.hmpc_second_opinion_review.restype = ctypes.c_int
+        self.lib.hmpc_second_opinion_review.argtypes = [ctypes.c_void_p]
+        self._check(self.lib.hmpc_second_opinion_review(self.handle))
+        v = [ctypes.c_int32() for _ in range(3)]
+        self.lib.hmpc_jit_stats.restype = ctypes.c_int
+        self.lib.hmpc_jit_stats.argtypes = [ctypes.c_void_p] + [ctypes.POINTER(ctypes.c_int32)] * 3
+        self._check(self.lib.hmpc_jit_stats(self.handle, *[ctypes.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def validate_kernels(self, x0, fix, stream=None):
+        """Runs the first-use checks of the compiled kernels now (``hmpc_validate_kernels``; torch CUDA tensors as in
+        ``solve_batch_device``) instead of inside the first solve call through each wave count."""
+        import torch
+        if stream is None:
+            stream = torch.cuda.current_stream().cuda_stream
+        self.lib.hmpc_validate_kernels.restype = ctypes.c_int
+        self.lib.hmpc_validate_kernels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+        self._check(self.lib.hmpc_validate_kernels(self.handle, x0.data_ptr(), 0 if x0.dim() == 1 else self.nx, fix.data_ptr(), fix.shape[0], ctypes.c_void_p(stream)))
+
     def kernel_info(self):
         """Kind of kernel that serves this problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming form,
-        2 built-in register kernel, 3 register kernel compiled for this shape at creation, 4 / 5 / 6 the run-time-sized kernel /
-        its streaming form / the register kernel compiled with this problem's sizes at creation (``hmpc_kernel_info``)."""
+        2 built-in register kernel, 4 / 5 / 6 the run-time-sized kernel / its streaming form / the register kernel compiled
+        with this problem's sizes at creation (``hmpc_kernel_info``)."""
         k = (ctypes.c_int32 * 3)()
         self.lib.hmpc_kernel_info.restype = ctypes.c_int
         self.lib.hmpc_kernel_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
