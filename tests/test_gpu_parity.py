@@ -939,6 +939,33 @@ def test_replayed_real_frontier():
     assert abs(a['obj'][full].min() - sol.objective) <= 1e-8 * (1 + sol.objective)
 
 
+def test_replay_frontier_at_n40_as_the_bench_times_it():
+    # BASELINE configs[3] at the size the bench times it: the replay frontier of ITS OWN tree -- the
+    # 320 nodes a cold-started search from x0 = [0, 0, 1, 0] solves at N = 40 plus its 161 leaves, bench.real_tree_frontier, untiled
+    # (481 nodes; the bench tiles them to 2048) -- against the oracle at the one tolerance, every polished record against the dense
+    # active-set solve; solved as one batch (two waves per node) and with one / four waves per node.
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import real_tree_frontier
+    hip = make_controller('cart_pole_with_walls', T=40, backend='hip')
+    orc = make_controller('cart_pole_with_walls', T=40, backend='oracle', threads=16)
+    x0, fix, parent = real_tree_frontier(hip, 2048, 0, None, spread=0.)
+    count = int(np.flatnonzero(parent[1:] == -1)[0]) + 1 if np.any(parent[1:] == -1) else len(fix)   # (the tiling starts over at the second root)
+    assert 470 <= count <= 490, count
+    x0, fix = x0[:count], fix[:count]
+    b = orc.qp.solve_batch(x0, fix)
+    assert 0.25 < (b['status'] == 0).mean() < 0.6
+    for waves in (None, '1', '4'):
+        if waves:
+            os.environ['HMPC_WAVES'] = waves
+        try:
+            a = hip.qp.solve_batch(x0, fix)
+        finally:
+            os.environ.pop('HMPC_WAVES', None)
+        _compare(hip, a, b, 40, fix, x0=x0)
+    assert hip.qp.jit_stats()[0] == 0
+
+
 def test_bounded_qp_accessors_on_gpu():
     # the reference's BoundedQP method set (bounded_qp.py:127-341) over the HIP backend, with the
     # identities of test_bounded_qp.py:104-189 (Farkas signs, dual objective = -sum rhs * multiplier, strong duality)
