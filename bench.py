@@ -809,7 +809,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                          'algorithmic_bytes_per_launch': bytes_per_qp * B,
-                         'algorithmic_bytes_per_qp': bytes_per_qp, 'kernel': 'hmpc_qp_kernel',
+                         'algorithmic_bytes_per_qp': bytes_per_qp, 'kernel': 'hmpc_qp_kernel', 'kernel_kinds_1_2_4_waves': list(ctrl.qp.kernel_info()), 'ilp_schedule_1_2_4_waves': list(ctrl.qp.kernel_recipe()),
                          'kernel_ms_avg': kernel_ms, 'grid': grid, 'lds_bytes_per_wg': lds},
             # secondary: algorithmic flops (per interior-point iteration T (7/3) (nx+nu)^3 + 2 nnz(A_c) (nx+nu)
             # = 1.2e5 for this workload) against the f64 vector peak (half of MI355X_MICROARCH.md's 157.3 TFLOP/s FP32)

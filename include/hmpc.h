@@ -321,10 +321,15 @@ int hmpc_lp_solve_batch(int32_t device, int32_t n, int32_t m, const double *A, c
  *   hmpc_kernel_info : which kernel serves the problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming
  *                      form, 2 built-in register kernel, 4 / 5 / 6 the run-time-sized kernel / its streaming form / the register
  *                      kernel compiled with this problem's sizes.
+ *   hmpc_kernel_recipe : 1 per wave count whose compiled kernel was built with the compiler's ILP schedule (8 - 15 % faster; only
+ *                      binaries listed in the cache's VALIDATED manifest, which tests/gpu_validate_ilp.py writes after running each of
+ *                      them against the oracle: that schedule produced most of the wrong binaries of rounds 4 and 5), 0: the
+ *                      compiler's default schedule -- the recipe of every kernel compiled for a problem nobody has validated.
  *   hmpc_jit_stats   : compiled kernels dropped by the nets; solve calls with a second opinion; batches on which it agreed.
  *   hmpc_jit_build_problem : everything hmpc_create would compile for this problem, ahead of time and without a GPU (the host
  *                      side of hmpc_create, nothing uploaded); paths: the shared objects, newline separated (may be NULL). */
 int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3);
+int hmpc_kernel_recipe(const hmpc_handle *h, int32_t *ilp3);
 int hmpc_jit_stats(const hmpc_handle *h, int32_t *dropped, int32_t *second_runs, int32_t *second_agreed);
 int hmpc_jit_build_problem(const hmpc_problem *problem, const hmpc_options *options, char *paths, int32_t paths_len);
 int hmpc_validate_kernels(hmpc_handle *h, const double *d_x0, int32_t x0_stride, const int8_t *d_fix, int32_t B, void *stream);

@@ -29,10 +29,17 @@ mld, objective, x0 = random_mld(nx=nx, nuc=nuc, nub=nub, seed=seed)
 ctrl = HybridModelPredictiveController(mld, T, objective, None, backend=_NoBackend())
 fix = np.full((6, T * nub), -1, np.int8)
 fix[1, :nub] = 0; fix[2, :2 * nub] = 0; fix[3, 0] = 1; fix[4, :3] = 0; fix[5, :T * nub // 2] = 0
+if os.environ.get('DBG_PREFIXES'):      # random prefixes instead (statuses AND the rays of the infeasible nodes are compared)
+    from helpers import random_prefix_frontier
+    fix = random_prefix_frontier(T, nub, int(os.environ['DBG_PREFIXES']), p_one=0.3)
+    fix[0, :] = -1
 b = OracleBatchedQP(ctrl.problem_data(), threads=8).solve_batch(x0, fix)
 hip = HipBatchedQP(ctrl.problem_data())
 a = hip.solve_batch(x0, fix)
-print('RESULT', 'ok' if np.array_equal(a['status'], b['status']) else 'WRONG', a['status'].tolist(), hip.kernel_info())
+inf = b['status'] == 1
+same = np.array_equal(a['status'], b['status'])
+rays = same and (not inf.any() or np.nanmax(np.abs(a['dual'][inf] - b['dual'][inf])) < 1e-6) and not np.isnan(a['dual'][inf]).any()
+print('RESULT', 'ok' if same and rays else 'WRONG', np.bincount(a['status'], minlength=4).tolist(), 'statuses equal', same, 'rays equal', bool(rays), hip.kernel_info())
 ''' % (HERE, spec)
 
 

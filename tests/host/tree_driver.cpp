@@ -154,6 +154,21 @@ int main(int argc, char **argv)
         }
     }
     printf("]\n");
+    {   // a node pruned WITHOUT a certificate (HMPC_ITERS_UNCERTIFIED) is counted, with the bound it carried before its solve:
+        // what hmpc_fleet_uncertified reports and what decides whether a search's optimum rests on such a prune
+        FleetTree t;
+        tree_reset_cold(t, nfix);
+        tree_begin_step(t, x0s.data(), nx);
+        t.lb[0] = 0.25;
+        t.cache.emplace(tree_key(t.fix.data(), 0), FleetResult{inf, 0.0, 0.0, 0, false, false, true});
+        const std::vector<int> pk{0};
+        if (tree_consume(t, pk, nfix, 0.0) != 0 || t.uncertified != 1 || t.unc_lb != 0.25 || t.lb[0] != inf || t.solves != 1) {
+            fprintf(stderr, "uncertified prune: not accounted for\n");
+            return 5;
+        }
+        tree_begin_step(t, x0s.data(), nx);
+        if (t.uncertified != 0 || t.unc_lb != inf) { fprintf(stderr, "uncertified prune: a step does not start clean\n"); return 5; }
+    }
     // (no dlclose: the OpenMP runtime the oracle brought in keeps worker threads alive)
     return 0;
 }

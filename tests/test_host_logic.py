@@ -1,5 +1,6 @@
 """Host-side mirror of the reference API: constructor checks, node <-> bounds, branching rule,
 selection rules, batched frontier mode, feedback().  Runs on the CPU oracle backend."""
+import os
 from copy import copy
 
 import numpy as np
@@ -135,3 +136,43 @@ def test_nonconverged_nodes_are_surfaced():
 
 def test_bounded_qp_accessor_interface():
     exercise_bounded_qp(make_controller('cart_pole_with_walls', T=10, backend='oracle'))
+
+
+def test_parity_flags_of_a_bench_line():
+    # bench.py puts everything that says "a kernel did not do what its sibling or the contract says" under ONE top-level key
+    # (the bench line had carried `statuses_equal: false` unnoticed for a round): undecided nodes anywhere in
+    # the line, status arrays or polished counts of two kernels on one workload that differ, compiled kernels the nets dropped
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    clean = {'nodes': {'not_converged': 0, 'compiled_kernels_dropped': 0}, 'other_configs': {'generic_vs_specialised': {'statuses_equal': True, 'polished_equal': True,
+             'specialised': {'not_converged': 0}, 'generic': {'not_converged': 0}}}}
+    assert bench.parity_flags(clean) == {'ok': True, 'not_converged': {}, 'statuses_or_polished_counts_differ': [], 'compiled_kernels_dropped': {}}
+    dirty = {'nodes': {'not_converged': 0, 'compiled_kernels_dropped': 1}, 'other_configs': {'generic_vs_specialised': {'statuses_equal': False, 'polished_equal': False,
+             'specialised': {'not_converged': 1}, 'generic': {'not_converged': 0}}}}
+    f = bench.parity_flags(dirty)
+    assert not f['ok'] and f['not_converged'] == {'other_configs.generic_vs_specialised.specialised': 1}
+    assert sorted(f['statuses_or_polished_counts_differ']) == ['other_configs.generic_vs_specialised.polished_equal', 'other_configs.generic_vs_specialised.statuses_equal']
+    assert f['compiled_kernels_dropped'] == {'nodes': 1}
+
+
+def test_uncertified_prunes_are_said_aloud():
+    # a node declared infeasible on the collapse of tau alone (HMPC_ITERS_UNCERTIFIED / bit 10 of the oracle's flags) prunes its
+    # subtree without a proof: the reference-shaped API warns (the reference's solver states infeasibility with a certificate,
+    # bounded_qp.py:216-228); the C++ fleet driver counts them (hmpc_fleet_uncertified; tests/host/tree_driver.cpp)
+    import warnings
+    ctrl = make_controller('cart_pole_with_walls', T=10, backend='oracle')
+    inner = ctrl.qp.solve_batch
+
+    def flagged(x0, fix, **kw):
+        r = inner(x0, fix, **kw)
+        r['uncertified'] = (r['status'] == 1).astype(np.int32)
+        return r
+    fix = np.zeros((1, 40), np.int8)
+    fix[0, 0] = 1                                              # (an infeasible node of this system)
+    assert inner(np.array([0., 0., .5, 0.]), fix)['status'][0] == 1 and inner(np.array([0., 0., .5, 0.]), fix)['uncertified'][0] == 0
+    ctrl.qp.solve_batch = flagged
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ctrl.solve_frontier(fix, np.array([0., 0., .5, 0.]))
+    assert any('WITHOUT a certificate' in str(x.message) for x in w)

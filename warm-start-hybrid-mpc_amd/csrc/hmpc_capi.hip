@@ -39,6 +39,7 @@ struct hmpc_cfg { // the kernel used for 1 / 2 / 4 waves per node, its LDS carve
     size_t lds = 0;
     int max_grid = 0;
     int sized = 0; // k is the run-time-sized kernel compiled with this problem's sizes (hmpc_jit_prepare_sized)
+    int ilp = 0;   // ... with the compiler's ILP schedule: a binary the cache's VALIDATED manifest lists (hmpc_jit.h: sched_flags)
     // FIRST-USE CHECK of a kernel compiled at hmpc_create: `ref` is the shipped kernel that would serve this wave count without
     // the run-time compiler; the first launch through this configuration solves its first few nodes with both and compares
     // statuses and objectives (hmpc_check_compiled).  A kernel that disagrees is dropped for the handle.
@@ -179,7 +180,7 @@ int upload_stage(hmpc_handle *h, const StageHost &s, SparseStage &d)
 }
 
 // Wave counts for which this problem gets a register kernel compiled with its sizes (hmpc_jit_prepare_sized): placeholders
-// (waves, kc, occ2) for hmpc_pick_kernel where the static row map holds the problem -- nx + nu <= 16, every [F G] row with
+// (waves, kc) for hmpc_pick_kernel where the static row map holds the problem -- nx + nu <= 16, every [F G] row with
 // at most two input coefficients, columns of at most HMPC_KC_STRIDE entries, at most 128 Gram entries with terms, at least one
 // binary, at most 16 row slots per lane.  The two cart-pole shapes have built-in instantiations, which hmpc_pick_kernel finds
 // itself; other problems leave jit empty and take the run-time-sized kernel.
@@ -195,8 +196,7 @@ void hmpc_jit_register_shapes(const DevProb &p, hmpc_kernel_choice (&jit)[3], si
         if (!hmpc_static_slots(p, 1 << c, kf, kb, kt)) continue;
         if (kt < 1) kt = 1;                 // (the row map keeps a terminal slot; a problem without terminal set leaves it empty)
         if (kf + kb + kt > 16) continue;    // (row state in registers: 4 doubles per slot and lane)
-        const int occ2 = (c == 0 && lds_cu / hmpc_lds_bytes(p, kc, 0) >= 6 && !getenv("HMPC_JIT_NO_OCC2")) ? 1 : 0;
-        jit[c] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, 1 << c, kc, 0, occ2};
+        jit[c] = {(hmpc_kernel_t)(uintptr_t)1, (hmpc_kernel_t)(uintptr_t)1, 1 << c, kc, 0};
     }
 }
 
@@ -244,7 +244,7 @@ bool hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
             int kf = 0, kb = 0, kt = 0;
             if (!hmpc_static_slots(p, k.waves, kf, kb, kt)) continue;
             if (kt < 1) kt = 1;
-            shapes[count] = hmpc_jit_shape{p.nx, p.nu, p.nub, kf, kb, kt, k.waves, k.kc, k.occ2, fields};
+            shapes[count] = hmpc_jit_shape{p.nx, p.nu, p.nub, kf, kb, kt, k.waves, k.kc, fields};
             slot[count++] = c;
             continue;
         }
@@ -255,14 +255,24 @@ bool hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
         int rs = p.Mpad / (WAVE << c), rs_max = 16;
         if (const char *e = getenv("HMPC_JIT_SIZED_ROWS")) rs_max = atoi(e);
         if (rs > rs_max) rs = 0;
-        shapes[count] = hmpc_jit_shape{k.big ? -1 : 0, -1, 0, rs, 0, 0, 1 << c, 0, 0, fields};
+        shapes[count] = hmpc_jit_shape{k.big ? -1 : 0, -1, 0, rs, 0, 0, 1 << c, 0, fields};
         slot[count++] = c;
+    }
+    // the ILP schedule for the binaries the VALIDATED manifest lists (hmpc_jit.h: sched_flags), the default schedule for all others
+    if (!getenv("HMPC_JIT_SCHED")) {
+        const uint64_t hsh = hmpc_jit::source_hash();
+        for (int i = 0; i < count; i++) {
+            hmpc_jit_shape probe = shapes[i];
+            probe.ilp = 1;
+            if (hmpc_jit::validated(hmpc_jit::name_of(probe, hsh))) shapes[i].ilp = 1;
+        }
     }
     std::vector<std::string> paths;
     std::string err;
     if (count) (void)hmpc_jit_build_all(shapes, count, paths, err);
     for (int i = 0; i < count; i++) {
         if (paths[i].empty()) continue;
+        cfg[slot[i]].ilp = shapes[i].ilp || (getenv("HMPC_JIT_SCHED") && std::string(getenv("HMPC_JIT_SCHED")) != "default");
         if (built) {                                                     // (dry run: built, not loaded)
             bool seen = false;
             for (const std::string &b : *built) seen |= b == paths[i];
@@ -569,6 +579,7 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
                 cf.k = ship;
                 cf.lds = hmpc_lds_bytes(p, ship.kc, ship.big);
                 cf.sized = 0;
+                cf.ilp = 0;
                 h->jit_rejected++;
                 ok = cf.lds <= lds_cu && (lds_max <= 0 || cf.lds <= (size_t)lds_max) && reserve(cf);
             }
@@ -700,6 +711,15 @@ extern "C" int hmpc_kernel_info(const hmpc_handle *h, int32_t *kind3)
         const hmpc_kernel_choice &k = h->cfg[c].k;
         kind3[c] = k.kc > 0 ? (h->cfg[c].sized ? 6 : 2) : (k.big ? 1 : 0) + (h->cfg[c].sized ? 4 : 0);
     }
+    return HMPC_OK;
+}
+
+// Which compiled kernels of this handle (1 / 2 / 4 waves per node) were built with the compiler's ILP schedule -- binaries listed in the
+// cache's VALIDATED manifest (csrc/hmpc_jit.h) --; 0: the default schedule, or a shipped kernel.
+extern "C" int hmpc_kernel_recipe(const hmpc_handle *h, int32_t *ilp3)
+{
+    if (!h || !ilp3) return fail(HMPC_EINVAL, "null argument");
+    for (int c = 0; c < 3; c++) ilp3[c] = h->cfg[c].sized ? h->cfg[c].ilp : 0;
     return HMPC_OK;
 }
 
@@ -881,9 +901,10 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
                            (const int32_t *)nullptr, w);
         HIPCHK(hipGetLastError());
     }
-    double hobj[3 * N];
+    double hobj[3 * N], hdob[3 * N];
     int32_t hst[3 * N];
     HIPCHK(hipMemcpyAsync(hobj, obj, 2 * N * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(hdob, dobj, 2 * N * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(hst, st, 2 * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     bool same = true;
@@ -894,6 +915,12 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
         if (sa == HMPC_OPTIMAL && sb == HMPC_OPTIMAL) {
             const double a = hobj[b], c = hobj[N + b];
             same = same && std::fabs(a - c) <= 1e-6 * (1.0 + std::fabs(a));
+        }
+        // (an infeasible node's ray is normalised to a unit largest entry: its dual objective is a scalar of the WHOLE ray -- the
+        // one wrong binary round 5 met that was not loud had right statuses and rays scaled by 1e-43, dual objectives off by 1e-2)
+        if (sa == HMPC_INFEASIBLE && sb == HMPC_INFEASIBLE) {
+            const double a = hdob[b], c = hdob[N + b];
+            same = same && (std::fabs(a - c) <= 1e-4 * std::fabs(a) + 1e-9) && c == c;
         }
     }
     // run 2: the HAND-DOWN instantiation of the compiled kernel (its own binary), every optimal node handed its own record:
@@ -925,6 +952,7 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
         cf.lds = cf.ref_lds;
         cf.max_grid = cf.ref_grid;
         cf.sized = 0;
+        cf.ilp = 0;
         cf.checked = -1;
         h->jit_rejected++;
     }
@@ -951,6 +979,7 @@ static void hmpc_second_opinion_review_impl(hmpc_handle *h, bool wait)
         cc.lds = cc.ref_lds;
         cc.max_grid = cc.ref_grid;
         cc.sized = 0;
+        cc.ilp = 0;
         cc.checked = -1;
         h->jit_rejected++;
     } else {

@@ -101,7 +101,7 @@ static inline size_t hmpc_lds_bytes(const DevProb &p, int kc, int big)
     d += dir;                                                             // w lam nuf
     d += M;                                                               // e (row vector: z / D / D.*rhs / dz in turn)
     d += T * nu + (big ? 0 : T * lms + (T + 1) * nxs);                    // dinv ; Lm Pr (global slab if big)
-    d += n + 2 * T * nx + n + (T + 1) * nx;                               // rd rdyn edyn g pv
+    d += n + T * nx + (T + 1) * nx + n + (T + 1) * nx;                    // rd rdyn edyn g pv
     d += dir + (dir > fscr ? dir : fscr);                                 // w1.. ; w2.. (doubles as factor scratch)
     d += (nx + 3) / 4 * 4 + nz + 40;                                      // q (padded to four) mv red
     d += nx;                                                              // x0

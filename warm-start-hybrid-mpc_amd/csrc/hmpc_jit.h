@@ -49,15 +49,19 @@ extern char **environ;
 
 struct hmpc_jit_shape {
     int nx, nu, nub, kf, kb, kt, nw, kc;
-    // two waves per SIMD (256 registers per lane instead of 512): pays where LDS holds more than four nodes per CU -- measured
-    // on a random MLD nx = 6, nu = 2 + 3, N = 12 (26.6 KB of LDS per node, six per CU): 657 k against 547 k QP/s; where only four
-    // fit (nx = 8, nu = 3 + 4, N = 10: 38.4 KB) the spills cost 13 % and buy nothing (tests/gpu_dev_jit_occupancy.py)
-    int occ2 = 0;
+    // (Round 4 also built the one-wave kernel for TWO waves per SIMD -- 256 registers per lane, amdgpu_waves_per_eu(2, 2) -- where LDS
+    // held six or more nodes per CU: 657 k against 547 k QP/s on a random MLD nx = 6, nu = 2 + 3, N = 12.  Withdrawn in round 5: at 256
+    // registers this kernel spills hundreds of bytes per lane, and THAT build came out of the compiler wrong, silently -- right
+    // statuses and iteration counts, the rays of 9 % of the infeasible nodes scaled by ~1e-43 (an entry nothing reads grown huge) --,
+    // right at -O1, with every other wave count, and in the 512-register build of the same source (profiles/r05_compiler_bisect.md).)
     // SIZED kernel (round 4): the run-time-sized kernel (nx = 0) or its streaming form (nx = -1) compiled with the integer
     // sizes of ONE problem as constants -- `sized` is the body of the HMPC_SIZED(p) macro, assignments to the fields of DevProb
     // (hmpc_sized_fields in hmpc_capi.hip); nu = -1 marks the instantiation (its symbols differ from the shipped kernels').
     // The same code paths with immediates for strides, trip counts and divisions: configs[4] 1.4x.
     std::string sized;
+    // compiled with the compiler's ILP schedule (-amdgpu-sched-strategy=iterative-ilp): only for binaries listed in the cache's
+    // VALIDATED manifest, see sched_flags
+    int ilp = 0;
 };
 
 namespace hmpc_jit {
@@ -127,21 +131,30 @@ inline std::string extra_flags()
     return f;
 }
 
-// Instruction scheduling for ILP (-amdgpu-sched-strategy=iterative-ilp): these kernels run ONE wave per SIMD, nothing hides a
-// latency but the schedule itself, and the compiler's default strategy schedules for occupancy first.  Measured on the kernels
-// compiled with the problem's sizes (profiles/r04_sched_ab.txt): N = 40, two waves per node 118 -> 130 k QP/s, configs[4]
-// 30.7 -> 32.1 k.  The register kernels with ONE wave per node (up to 15 row slots per lane) take it together with the
-// v_readlane broadcasts (-DHMPC_DPP_FEW: DPP only up to 8 slots, the rule of the shipped kernels): with the DPP broadcasts the
-// longer live ranges spill (headline 512 -> 524 k QP/s at 84 -> 236 B of scratch, the hand-down instantiation LOSES), with
-// v_readlane the same kernel has NO scratch and runs 563 k QP/s (profiles/r04_sched_ab.txt).  Kernels built for two waves
-// per SIMD (256 registers) keep the default schedule (ILP: 520 -> 451 k QP/s).  HMPC_JIT_SCHED=<strategy> | default: for every
-// kernel; a strategy in HMPC_JIT_FLAGS likewise.
+// Instruction scheduling.  These kernels run ONE wave per SIMD: nothing hides a latency but the schedule itself, and the compiler's
+// default strategy schedules for occupancy first.  Its ILP strategy (-amdgpu-sched-strategy=iterative-ilp) is worth 8 - 15 %
+// (round 4: headline 489 -> 563 k QP/s, N = 40 118 -> 130 k, configs[4] 30.7 -> 32.1 k) -- AND it is the recipe most of the wrong
+// binaries of rounds 4 and 5 were compiled with: an experimental scheduler in front of a register allocator that has to spill
+// (profiles/r05_compiler_bisect.md; round 5's sweep of 29 problems x 3 wave counts, profiles/r05_variant_sweep.txt: three
+// problems with a wrong kernel under the ILP schedule -- one of them did not come back from a launch at all --, the same kernels
+// right under the default schedule).  So:
+//   * the DEFAULT recipe of a kernel compiled at run time is the compiler's default schedule;
+//   * the ILP schedule is used for a binary only if its NAME -- which covers the problem's sizes, the kernel sources, the flags,
+//     the architecture and the compiler's identity -- is listed in the cache's VALIDATED manifest: written by
+//     tests/gpu_validate_ilp.py, which runs every such binary (1 / 2 / 4 waves, cold and hand-down instantiation) against the
+//     oracle in a process of its own under a watchdog.  The manifest is tracked with the sources; any edit of the kernel, the
+//     flags or the toolchain changes the names and with them falls back to the default recipe until the validation has run again.
+// The register kernels take DPP broadcasts up to 8 row slots per lane and v_readlane beyond, in both recipes (-DHMPC_DPP_FEW: the
+// rule of the shipped kernels).  HMPC_JIT_SCHED=<strategy> | default forces one
+// schedule for every kernel (experiments, and the validation run itself); a strategy in HMPC_JIT_FLAGS likewise.
 inline std::string sched_flags(const hmpc_jit_shape &s)
 {
-    const bool one_wave_register = s.nx > 0 && s.nw == 1 && !s.occ2;
-    std::string f = one_wave_register ? "-DHMPC_DPP_FEW" : "";
+    // (every register kernel: round 4 gave the kernels with two and four waves per node DPP broadcasts whatever their slot count;
+    // round 5's sweep met a two-wave kernel with 13 slots that comes out wrong with them and right with v_readlane, as round 4 had
+    // met a one-wave kernel: the shipped kernels' rule for all)
+    std::string f = s.nx > 0 ? "-DHMPC_DPP_FEW" : "";
     if (extra_flags().find("amdgpu-sched-strategy") != std::string::npos) return f;
-    std::string strat = s.occ2 ? "default" : "iterative-ilp";
+    std::string strat = s.ilp ? "iterative-ilp" : "default";
     if (const char *sc = getenv("HMPC_JIT_SCHED")) strat = sc;
     if (strat != "default") f += std::string(f.empty() ? "" : " ") + "-mllvm -amdgpu-sched-strategy=" + strat;
     return f;
@@ -223,7 +236,7 @@ inline std::string name_of(const hmpc_jit_shape &s, uint64_t hsh0)
     const std::string fl = sched_flags(s) + "|" + safe_flags();
     const uint64_t hsh = hsh0 ^ fnv(fl); // (the schedule and the switched-off passes are part of the key)
     if (!s.sized.empty() && s.nx > 0) {
-        snprintf(b, sizeof b, "hmpc_s_reg_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, s.occ2 ? "_o2" : "",
+        snprintf(b, sizeof b, "hmpc_s_reg_%d_%d_%d_%d_%d_%d_w%d_kc%d%s_%016llx_%016llx", s.nx, s.nu, s.nub, s.kf, s.kb, s.kt, s.nw, s.kc, "",
                  (unsigned long long)fnv(s.sized), (unsigned long long)hsh);
         return b;
     }
@@ -251,6 +264,22 @@ inline std::vector<std::string> scrubbed_environment()
 }
 
 // Starts the compilation of one shape (returns the child's pid, 0 if the object is in the cache already, -1 on failure).
+// Is this binary (by the name of its cache entry) in the VALIDATED manifest of the cache it would be loaded from, or of the
+// library's own jit_cache (the manifest the tree ships)?  One name per line, '#' comments.
+inline bool validated(const std::string &name)
+{
+    for (const std::string &dir : {cache_dir(), dir_of_library() + "/jit_cache"}) {
+        if (dir.empty()) continue;
+        std::ifstream in(dir + "/VALIDATED");
+        std::string line;
+        while (std::getline(in, line)) {
+            while (!line.empty() && (line.back() == '\r' || line.back() == ' ')) line.pop_back();
+            if (line == name) return true;
+        }
+    }
+    return false;
+}
+
 inline std::string build_tag(unsigned seq) // (temporary files of one build: process id and a per-process counter -- two threads
 {                                          //  of one process may compile the same problem at the same time)
     char tag[48];
@@ -282,7 +311,7 @@ inline pid_t start_build(const hmpc_jit_shape &s, const std::string &cache, uint
         if (!out) { err = "cannot write " + src; return -1; }
     }
     // the compiler runs as a CHILD process (posix_spawn, as Python's subprocess does): nothing of this process is replaced
-    const std::string cmd = compiler() + " --offload-arch=" + arch() + " -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags(s) + (s.occ2 ? "'-DHMPC_KERNEL_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))' " : "") + " -I '" + include_dir() + "' -I '" +
+    const std::string cmd = compiler() + " --offload-arch=" + arch() + " -O3 -fPIC -std=c++17 -ffp-contract=fast -Wno-pass-failed " + quoted_flags(s) + " -I '" + include_dir() + "' -I '" +
                             source_dir() + "' -shared -Wl,-Bsymbolic -o '" + tmp + "' '" + src + "' > '" + base + tag + ".log' 2>&1 && mv '" + tmp + "' '" + so + "'";
     pid_t pid = -1;
     const char *argv[] = {"sh", "-c", cmd.c_str(), nullptr};

@@ -65,6 +65,9 @@
 #ifndef HMPC_STABLE_DEN
 #define HMPC_STABLE_DEN 1
 #endif
+#ifndef HMPC_PAIR // (0: A/B builds without the paired solve of the register kernels, kkt_solve_reg_pair)
+#define HMPC_PAIR 1
+#endif
 #ifndef HMPC_NARROW_PANEL // (0: diagnostic builds without the narrow panel of stages whose binaries are all fixed)
 #define HMPC_NARROW_PANEL 1
 #endif
@@ -80,6 +83,13 @@
 #define HMPC_KERNEL_ATTR
 #endif
 #define DEV __device__ __forceinline__
+// Scheduling fence around a batch of LDS loads in the register kernels (ccol_dot, the Gram phase of factor_reg): keeps the
+// compiler's default scheduler from pairing every load with its use.  -DHMPC_NO_FENCE: without (A/B under the ILP schedule).
+#ifdef HMPC_NO_FENCE
+#define HMPC_FENCE() do { } while (0)
+#else
+#define HMPC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // Diagnostic build only (-DHMPC_STAMPS): cycle stamps per phase of the interior-point loop,
 // accumulated for node 0 into the trace buffer.  No stamp executes in the shipped kernel.
@@ -475,10 +485,10 @@ template <class D> DEV double ccol_dot(const DevProb &p, const Lds &S, int t, in
             for (int q = 0; q < H; q++) idx[q] = ci[hb + q];
 #pragma unroll
             for (int q = 0; q < H; q++) cc[q] = cv[hb + q];
-            __builtin_amdgcn_sched_barrier(0);
+            HMPC_FENCE();
 #pragma unroll
             for (int q = 0; q < H; q++) { HMPC_CHK(idx[q] >= 0 && idx[q] < p.mreg && j >= 0 && j < D::nz(p) && t >= 0 && t < p.T, 1); ee[q] = eb[idx[q]]; }
-            __builtin_amdgcn_sched_barrier(0);
+            HMPC_FENCE();
 #pragma unroll
             for (int q = 0; q < H; q++) {
                 if (q & 1) a1 += cc[q] * ee[q];
@@ -1528,10 +1538,10 @@ template <class D> DEV int factor_reg(const DevProb &p, const Lds &S, int lane F
                         idx[q] = S.L0.grow[qq];
                         gv[q] = S.L0.gval[qq];
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                    HMPC_FENCE();
 #pragma unroll
                     for (int q = 0; q < GH; q++) { HMPC_CHK(idx[q] >= 0 && idx[q] < p.mreg, 2); dv[q] = Dt[idx[q]]; }
-                    __builtin_amdgcn_sched_barrier(0);
+                    HMPC_FENCE();
 #pragma unroll
                     for (int q = 0; q < GH; q++) {
                         const double term = hb + q < glen ? gv[q] * dv[q] : 0.0;
@@ -2454,6 +2464,293 @@ DEV void kkt_solve_reg(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm
     FSTAMP(10);
 }
 
+// ---------------------------------------------------------------------------------------------
+// TWO solves of one iteration in one pair of sweeps (round 5; register kernels, interior-point iterations only).  The constant
+// direction (right-hand side (0; f; h): what kkt_solve_reg(.., nullptr, 0, true, nullptr, 0, true, S.w1 ..) computes) and the
+// affine direction of the predictor (.., S.rd, -1, false, S.rdyn, -1, false, S.w2 ..) depend on the factorisation only, not on
+// each other.  A sweep is a chain of broadcast / multiply-add steps on wave 0 that nothing overlaps with (one wave per SIMD):
+// two right-hand sides through the same chain share every multiplier fetch and give the chain's latency something to hide
+// behind.  Row phases, column products and the multipliers of the equalities are what they are in two separate solves, in
+// another order: the arithmetic of each direction is unchanged.
+//   On entry : R.D holds D, S.g the factorisation's mb, S.rd / S.rdyn the residuals, S.w the iterate.
+//   On exit  : S.w1, S.lam1, S.nuf1 the constant direction; S.w2, S.lam2, S.nuf2 the affine direction; S.e the affine
+//              direction's dz; returns this lane's part of sum dz1^2 / D over its rows (the tau step's denominator).
+//   Storage  : the affine direction's stage gradient lives in S.w2 itself (the backward sweep reads stage t - 1 before it parks
+//              stage t's y there), its p_t in S.edyn (dead outside the refinement; carved (T + 1) nx long for this).
+// ---------------------------------------------------------------------------------------------
+template <class D, int RS, class RM>
+DEV double kkt_solve_reg_pair(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, double tau FSTAMP_ARGS)
+{
+    constexpr int NX = D::kNX, NU = D::kNU, NUB = D::kNUB, NUC = NU - NUB, NZ = NX + NU;
+    constexpr int NXS = NX * (NX + 1) / 2, LMS = LM_STAGE(NX, NU);
+    const int T = p.T;
+    const int nslot = RS;
+    ldsd *pv2 = S.edyn;
+    FSTAMP_DECL;
+    LANE_OPAQUE(lane);
+    // ---- constant direction: e = D h ; S.g <- mb - C' e ----
+    ROWS_BEGIN(k, rw)
+        S.e[rw.e] = R.D(k, rw.e) * rm.h(p, S, k, rw);
+    ROWS_END
+    __syncthreads();
+    term_cols<D, RM>(p, S, lane, S.e);
+    for (int o = lane; o < T * NZ; o += D::kNT) {
+        const int t = o / NZ, j = o - t * NZ;
+        S.g[o] = S.g[o] - ccol_dot<D>(p, S, t, j, S.e);
+    }
+    for (int o = lane; o < (T + 1) * NX; o += D::kNT) S.pv[o] = 0.0;
+    __syncthreads();
+    // ---- affine direction: e = z - D rc (the predictor's right-hand side) ; S.w2 <- rd - C' e ----
+    ROWS_BEGIN(k, rw)
+        double v = 0;
+        const double d = R.D(k, rw.e);
+        if (d != 0.0) {
+            const double sr = R.s(k, rw.e), zr = d * sr;
+            const double rc = sr - rm.h(p, S, k, rw) * tau + rm.dot(p, S, k, rw, S.w); // row residual
+            const double dsr = sr * zr;
+            v = dsr * frcp(sr) - 1.0 * (d * rc);
+        }
+        S.e[rw.e] = v;
+        R.dz(k, rw.e) = v; // (kept: S.e carries the constant direction's dz for a while below)
+    ROWS_END
+    __syncthreads();
+    term_cols<D, RM>(p, S, lane, S.e);
+    for (int o = lane; o < T * NZ; o += D::kNT) {
+        const int t = o / NZ, j = o - t * NZ;
+        const double a = -1.0 * S.rd[o] + ccol_dot<D>(p, S, t, j, S.e);
+        S.w2[o] = 0.0 - a;
+    }
+    for (int o = lane; o < T * NX; o += D::kNT) {
+        const int t = o / NX, i = o - t * NX;
+        double a = 0.0;
+#pragma unroll
+        for (int l = 0; l < NX; l++) a += S.Pr[(t + 1) * NXS + sym(i, l)] * (-1.0 * S.rdyn[t * NX + l]);
+        pv2[o] = a;
+    }
+    double pvrA = 0.0, pvrB = 0.0; // lane i < NX: p_{t+1}[i] of the two directions
+    if (lane < NX) {
+        pvrB = -(-1.0 * S.rd[T * NZ + lane]);
+        pv2[T * NX + lane] = pvrB;
+    }
+    __syncthreads();
+    FSTAMP(6);
+    LANE_OPAQUE(lane);
+    if (D::kNW == 1 || lane < WAVE) { // backward sweep (wave 0), both directions
+        double ABcol[NX];
+#pragma unroll
+        for (int l = 0; l < NX; l++) ABcol[l] = lane < NZ ? S.AB[l * NZ + lane] : 0.0;
+        const int rowoff = lane < NX ? lane * NU : lane < NZ ? LM_U(NX, NU, lane - NX, 0) : 0;
+        const int rowlen = lane < NX ? NU : lane < NZ ? lane - NX : 0;
+        const int gl = lane < NZ ? lane : 0, bl = (lane >= NX + NUC && lane < NZ) ? lane - NX - NUC : 0;
+        const int pl = lane < NX ? lane : 0;
+        double mrow_n[NU], mpreA_n, mpreB_n, qcA_n, qcB_n;
+        int f_n;
+        {
+            const ldsd *row = S.Lm + (T - 1) * LMS + rowoff;
+#pragma unroll
+            for (int j = 0; j < NU; j++) mrow_n[j] = row[j];
+            mpreA_n = S.g[(T - 1) * NZ + gl];
+            mpreB_n = S.w2[(T - 1) * NZ + gl];
+            f_n = S.fix[(T - 1) * NUB + bl];
+            qcA_n = S.pv[(T - 1) * NX + pl];
+            qcB_n = pv2[(T - 1) * NX + pl];
+        }
+        for (int t = T - 1; t >= 0; t--) {
+            double mrow[NU];
+#pragma unroll
+            for (int j = 0; j < NU; j++) mrow[j] = j < rowlen ? mrow_n[j] : 0.0;
+            const double mpreA = lane < NZ ? mpreA_n : 0.0, mpreB = lane < NZ ? mpreB_n : 0.0;
+            const int f = (lane >= NX + NUC && lane < NZ) ? f_n : -1;
+            const double qvA = pvrA + qcA_n, qvB = pvrB + qcB_n;
+            {
+                const int tn = t > 0 ? t - 1 : 0; // the last round fetches stage 0 again (unused)
+                const ldsd *row = S.Lm + tn * LMS + rowoff;
+#pragma unroll
+                for (int j = 0; j < NU; j++) mrow_n[j] = row[j];
+                mpreA_n = S.g[tn * NZ + gl];
+                mpreB_n = S.w2[tn * NZ + gl];
+                f_n = S.fix[tn * NUB + bl];
+                qcA_n = S.pv[tn * NX + pl];
+                qcB_n = pv2[tn * NX + pl];
+            }
+            double vA = mpreA, vB = mpreB;
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                vA += ABcol[l] * bcast16<D>(qvA, l);
+                vB += ABcol[l] * bcast16<D>(qvB, l);
+            }
+            if (f >= 0) { vA = (f == 1) ? -1.0 : 0.0; vB = 0.0; }
+#pragma unroll
+            for (int j = 0; j < NUC; j++) {
+                vA -= mrow[j] * bcast16<D>(vA, NX + j);
+                vB -= mrow[j] * bcast16<D>(vB, NX + j);
+            }
+            if (!((S.fullfix >> t) & 1ull)) {
+#pragma unroll
+                for (int j = NUC; j < NU; j++) {
+                    vA -= mrow[j] * bcast16<D>(vA, NX + j);
+                    vB -= mrow[j] * bcast16<D>(vB, NX + j);
+                }
+            }
+            if (lane >= NX && lane < NZ) { S.w1[t * NZ + lane] = vA; S.w2[t * NZ + lane] = vB; }
+            pvrA = vA;
+            pvrB = vB;
+            if (lane < NX) { S.pv[t * NX + lane] = vA; pv2[t * NX + lane] = vB; }
+        }
+    }
+    __syncthreads();
+    FSTAMP(7);
+    LANE_OPAQUE(lane);
+    if (D::kNW == 1 || lane < WAVE) { // forward sweep (wave 0), both directions
+        double ABrow[NZ];
+#pragma unroll
+        for (int l = 0; l < NZ; l++) ABrow[l] = lane < NX ? S.AB[lane * NZ + l] : 0.0;
+        double xrA = lane < NX ? S.x0[lane] : 0.0, xrB = 0.0;
+        const int cl = lane < NU ? lane : 0, pl = lane < NX ? lane : 0;
+        double lx_n[NX], lcol_n[NU], dinv_n, yA_n, yB_n, cdy_n;
+        {
+            const ldsd *colp = S.Lm + cl;
+#pragma unroll
+            for (int l = 0; l < NX; l++) lx_n[l] = colp[LM_X(NX, NU, l, 0)];
+#pragma unroll
+            for (int i = 1; i < NU; i++) lcol_n[i] = colp[LM_U(NX, NU, i, 0)];
+            dinv_n = S.dinv[cl];
+            yA_n = S.w1[NX + cl];
+            yB_n = S.w2[NX + cl];
+            cdy_n = S.rdyn[pl];
+        }
+        for (int t = 0; t < T; t++) {
+            double lx[NX], lcol[NU];
+#pragma unroll
+            for (int l = 0; l < NX; l++) lx[l] = lane < NU ? lx_n[l] : 0.0;
+            lcol[0] = 0.0;
+#pragma unroll
+            for (int i = 1; i < NU; i++) lcol[i] = lane < i ? lcol_n[i] : 0.0;
+            double curA = lane < NU ? dinv_n * yA_n : 0.0, curB = lane < NU ? dinv_n * yB_n : 0.0;
+            double xnA = 0.0, xnB = lane < NX ? -1.0 * cdy_n : 0.0;
+            {
+                const int tn = t + 1 < T ? t + 1 : t;
+                const ldsd *colp = S.Lm + tn * LMS + cl;
+#pragma unroll
+                for (int l = 0; l < NX; l++) lx_n[l] = colp[LM_X(NX, NU, l, 0)];
+#pragma unroll
+                for (int i = 1; i < NU; i++) lcol_n[i] = colp[LM_U(NX, NU, i, 0)];
+                dinv_n = S.dinv[tn * NU + cl];
+                yA_n = S.w1[tn * NZ + NX + cl];
+                yB_n = S.w2[tn * NZ + NX + cl];
+                cdy_n = S.rdyn[tn * NX + pl];
+            }
+#pragma unroll
+            for (int l = 0; l < NX; l++) {
+                const double xlA = bcast16<D>(xrA, l), xlB = bcast16<D>(xrB, l);
+                curA += lx[l] * xlA;
+                curB += lx[l] * xlB;
+                xnA += ABrow[l] * xlA;
+                xnB += ABrow[l] * xlB;
+            }
+#pragma unroll
+            for (int j = NU - 1; j >= 0; j--) {
+                const double ujA = bcast16<D>(curA, j), ujB = bcast16<D>(curB, j);
+                curA -= lcol[j] * ujA;
+                curB -= lcol[j] * ujB;
+                xnA -= ABrow[NX + j] * ujA;
+                xnB -= ABrow[NX + j] * ujB;
+            }
+            if (lane < NX) { S.w1[t * NZ + lane] = xrA; S.w2[t * NZ + lane] = xrB; }
+            if (lane < NU) { S.w1[t * NZ + NX + lane] = -curA; S.w2[t * NZ + NX + lane] = -curB; }
+            xrA = xnA;
+            xrB = xnB;
+        }
+        if (lane < NX) { S.w1[T * NZ + lane] = xrA; S.w2[T * NZ + lane] = xrB; }
+    }
+    __syncthreads();
+    FSTAMP(9);
+    LANE_OPAQUE(lane);
+    // equality multipliers lam_t = -(P_t x_t + p_t) of both directions ; the constant direction's dz = D (C w1) - D h into S.e
+    for (int o = lane; o < (T + 1) * NX; o += D::kNT) {
+        const int t = o / NX, i = o - t * NX;
+        double a = S.pv[o], b = pv2[o];
+#pragma unroll
+        for (int l = 0; l < NX; l++) {
+            const double pr = S.Pr[t * NXS + sym(i, l)];
+            a += pr * S.w1[t * NZ + l];
+            b += pr * S.w2[t * NZ + l];
+        }
+        S.lam1[o] = -a;
+        S.lam2[o] = -b;
+    }
+    double q2 = 0.0;
+    ROWS_BEGIN(k, rw)
+        const double d = R.D(k, rw.e);
+        double z1 = 0.0;
+        if (d != 0.0) { // inactive rows keep e = 0
+            z1 = d * rm.dot(p, S, k, rw, S.w1) - d * rm.h(p, S, k, rw);
+            q2 += z1 * z1 * frcp(d);
+        }
+        S.e[rw.e] = z1;
+    ROWS_END
+    __syncthreads();
+    term_cols<D, RM>(p, S, lane, S.e);
+    for (int o = lane; o < T * NUB; o += D::kNT) { // multipliers of the fixed binaries from the stationarity row of their component
+        const int t = o / NUB, b = o - t * NUB;
+        double a = 0;
+        if (S.fix[o] >= 0) {
+            const int c = NX + NUC + b;
+#pragma unroll
+            for (int j = 0; j < NZ; j++) a -= S.P[c * NZ + j] * S.w1[t * NZ + j];
+            a -= ccol_dot<D>(p, S, t, c, S.e);
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += S.AB[l * NZ + c] * S.lam1[(t + 1) * NX + l];
+        }
+        S.nuf1[o] = a;
+    }
+    if (lane < NX) { // lam_0 from the stationarity row of x_0 (see kkt_solve)
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NZ; j++) a -= S.P[lane * NZ + j] * S.w1[j];
+        a -= ccol_dot<D>(p, S, 0, lane, S.e);
+#pragma unroll
+        for (int l = 0; l < NX; l++) a += S.AB[l * NZ + lane] * S.lam1[NX + l];
+        S.lam1[lane] = a;
+    }
+    __syncthreads();
+    // the affine direction's dz = D (C w2) - e into S.e (e was kept in the rows' dz slots)
+    ROWS_BEGIN(k, rw)
+        const double d = R.D(k, rw.e);
+        double z2 = 0.0;
+        if (d != 0.0) z2 = d * rm.dot(p, S, k, rw, S.w2) - R.dz(k, rw.e);
+        S.e[rw.e] = z2;
+    ROWS_END
+    __syncthreads();
+    term_cols<D, RM>(p, S, lane, S.e);
+    for (int o = lane; o < T * NUB; o += D::kNT) {
+        const int t = o / NUB, b = o - t * NUB;
+        double a = 0;
+        if (S.fix[o] >= 0) {
+            const int c = NX + NUC + b;
+            a = -1.0 * S.rd[t * NZ + c];
+#pragma unroll
+            for (int j = 0; j < NZ; j++) a -= S.P[c * NZ + j] * S.w2[t * NZ + j];
+            a -= ccol_dot<D>(p, S, t, c, S.e);
+#pragma unroll
+            for (int l = 0; l < NX; l++) a += S.AB[l * NZ + c] * S.lam2[(t + 1) * NX + l];
+        }
+        S.nuf2[o] = a;
+    }
+    if (lane < NX) {
+        double a = -1.0 * S.rd[lane];
+#pragma unroll
+        for (int j = 0; j < NZ; j++) a -= S.P[lane * NZ + j] * S.w2[j];
+        a -= ccol_dot<D>(p, S, 0, lane, S.e);
+#pragma unroll
+        for (int l = 0; l < NX; l++) a += S.AB[l * NZ + lane] * S.lam2[NX + l];
+        S.lam2[lane] = a;
+    }
+    __syncthreads();
+    FSTAMP(10);
+    return q2;
+}
+
 template <class D, int RS, class RM>
 DEV void kkt_dispatch(const DevProb &p, const Lds &S, Rows<RS> &R, const RM &rm, int lane, const ldsd *gsrc, double gs, bool usex0,
                       const ldsd *csrc, double cs, bool useb, ldsd *dw, ldsd *dlam, ldsd *dnuf FSTAMP_ARGS)
@@ -2921,20 +3218,34 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 for (int o = lane; o < T * nz; o += D::kNT) S.rd[o] = S.g[o];
             }
         }
+        // (register kernels, interior-point iterations: the constant direction and the predictor's affine direction in ONE pair
+        // of sweeps, kkt_solve_reg_pair; -DHMPC_PAIR=0: two solves as before)
+        constexpr bool kPair = D::kNX > 0 && HMPC_PAIR != 0;
+        static_assert(!kPair || HMPC_STABLE_DEN, "the paired solve hands the denominator's row sum back");
+        double q2_pair = 0.0;
+        bool paired = false;
         if (mode != 3) {
-            LANE_OPAQUE(lane);
-            ROWS_BEGIN(k, rw)
-                const double d = R.D(k, rw.e);
-                double v = d * rm.h(p, S, k, rw); // right-hand side of the constant direction
-                if (mode != 0) v = d >= 1.0 ? v - R.dz(k, rw.e) : d * R.dz(k, rw.e);
-                S.e[rw.e] = v;
-            ROWS_END
-            if (mode == 2)
-                for (int o = lane; o < T * nz; o += D::kNT) S.g[o] = S.rd[o];
-            __syncthreads();
+            if constexpr (kPair) {
+                if (mode == 0) {
+                    q2_pair = kkt_solve_reg_pair<D, RS, RM>(p, S, R, rm, lane, tau FSTAMP_PASS);
+                    paired = true;
+                }
+            }
+            if (!paired) {
+                LANE_OPAQUE(lane);
+                ROWS_BEGIN(k, rw)
+                    const double d = R.D(k, rw.e);
+                    double v = d * rm.h(p, S, k, rw); // right-hand side of the constant direction
+                    if (mode != 0) v = d >= 1.0 ? v - R.dz(k, rw.e) : d * R.dz(k, rw.e);
+                    S.e[rw.e] = v;
+                ROWS_END
+                if (mode == 2)
+                    for (int o = lane; o < T * nz; o += D::kNT) S.g[o] = S.rd[o];
+                __syncthreads();
 
-            // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
-            kkt_dispatch<D, RS>(p, S, R, rm, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+                // ---------------- constant direction: rhs = (0 ; f ; h) ----------------
+                kkt_dispatch<D, RS>(p, S, R, rm, lane, nullptr, 0.0, true, nullptr, 0.0, true, S.w1, S.lam1, S.nuf1 FSTAMP_PASS);
+            }
         }
         if (mode != 0) {
             // ---------------- polish: multiplier step, verification, next pass ----------------
@@ -3091,11 +3402,13 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
         // 0.046 in one step and the dual residual rose from 5e-8 to 3e-5 (profiles/r04_den_cancellation.txt).
         double den;
         if constexpr (HMPC_STABLE_DEN) {
-            double q1 = dPd<D>(p, S, lane, S.w1, 1.0 / tau), q2 = 0.0;
-            ROWS_BEGIN(k, rw)
-                const double d = R.D(k, rw.e);
-                if (d != 0.0) { const double z1 = S.e[rw.e]; q2 += z1 * z1 * frcp(d); } // (S.e: the constant direction's dz)
-            ROWS_END
+            double q1 = dPd<D>(p, S, lane, S.w1, 1.0 / tau), q2 = q2_pair;
+            if (!paired) {
+                ROWS_BEGIN(k, rw)
+                    const double d = R.D(k, rw.e);
+                    if (d != 0.0) { const double z1 = S.e[rw.e]; q2 += z1 * z1 * frcp(d); } // (S.e: the constant direction's dz)
+                ROWS_END
+            }
             double v[2] = {q1, q2};
             const int op[2] = {0, 0};
             block_reduce<D, 2>(v, op, S.red, lane);
@@ -3117,22 +3430,24 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
             const double lin = pass == 0 ? 1.0 : 1.0 - sigma;
             const double dkap_rhs = tau * kap + (pass ? dtau_a * dkap_a - sigma * mu : 0.0);
             LANE_OPAQUE(lane);
-            __syncthreads();
-            ROWS_BEGIN(k, rw)
-                double v = 0;
-                const double d = R.D(k, rw.e);
-                if (d != 0.0) { // active row
-                    const double sr = R.s(k, rw.e), zr = d * sr;
-                    const double rc = sr - rm.h(p, S, k, rw) * tau + rm.dot(p, S, k, rw, S.w); // row residual
-                    const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
-                    v = dsr * frcp(sr) - lin * (d * rc); // d (-lin rc + dsr / z) with z = d s
-                }
-                S.e[rw.e] = v;
-            ROWS_END
-            __syncthreads();
-            STAMP(4);
-            kkt_dispatch<D, RS>(p, S, R, rm, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
-            STAMP(3);
+            if (!(paired && pass == 0)) { // (the affine direction of a paired iteration is in place already)
+                __syncthreads();
+                ROWS_BEGIN(k, rw)
+                    double v = 0;
+                    const double d = R.D(k, rw.e);
+                    if (d != 0.0) { // active row
+                        const double sr = R.s(k, rw.e), zr = d * sr;
+                        const double rc = sr - rm.h(p, S, k, rw) * tau + rm.dot(p, S, k, rw, S.w); // row residual
+                        const double dsr = sr * zr + (pass ? R.prod(k, rw.e) - sigma * mu : 0.0);
+                        v = dsr * frcp(sr) - lin * (d * rc); // d (-lin rc + dsr / z) with z = d s
+                    }
+                    S.e[rw.e] = v;
+                ROWS_END
+                __syncthreads();
+                STAMP(4);
+                kkt_dispatch<D, RS>(p, S, R, rm, lane, S.rd, -lin, false, S.rdyn, -lin, false, S.w2, S.lam2, S.nuf2 FSTAMP_PASS);
+                STAMP(3);
+            }
             double g2 = 0;
             g2 = wPv<D>(p, S, lane, S.w2);
             double fyhz2 = lin_obj<D>(p, S, rm, lane, S.lam2, S.nuf2, S.e);
@@ -3473,7 +3788,7 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
         const int nxs = nx * (nx + 1) / 2;
         S.Lm = take(D::kBig ? 0 : T * LM_STAGE(nx, nu)); S.dinv = take(T * nu); S.Pr = take(D::kBig ? 0 : (T + 1) * nxs);
         S.LmG = p.fac_ws + (size_t)blockIdx.x * p.fac_stride; S.PrG = S.LmG + (size_t)T * LM_STAGE(nx, nu);
-        S.rd = take(n); S.rdyn = take(T * nx); S.edyn = take(T * nx); S.g = take(n); S.pv = take((T + 1) * nx);
+        S.rd = take(n); S.rdyn = take(T * nx); S.edyn = take((T + 1) * nx); S.g = take(n); S.pv = take((T + 1) * nx); // (edyn: one stage longer, kkt_solve_reg_pair keeps a p_t there)
         S.w1 = take(n); S.lam1 = take((T + 1) * nx); S.nuf1 = take(T * nub);
         // the second direction is dead while a factorisation runs: its storage doubles as the
         // factorisation scratch (stage matrix, carried identity block, Pn [A B])
@@ -3584,7 +3899,9 @@ hmpc_qp_kernel(const DevProb p_arg, const double *__restrict__ x0g, int x0_strid
     // (MAXITER / NUMERICAL), listed in warm.pend, are solved again by the shipped kernel -- this one, launched through its
     // hand-down instantiation so that the cold kernels do not carry the list mode; a node is handed what the first launch
     // handed it (warm.index), nothing else differs from a regular launch.
-    for (int slot = blockIdx.x; slot < Bn;) {
+    // (guard: a workgroup never takes more nodes than the launch has -- a binary whose node counter came out of the compiler wrong
+    // has been seen to spin here for good, profiles/r05_compiler_bisect.md; with the guard it ends, loudly wrong)
+    for (int slot = blockIdx.x, guard = 0; slot < Bn && guard <= Bn; guard++) {
         // `order` (optional): the nodes sorted by the number of fixed binaries, shallow first -- shallow nodes take more
         // iterations (correlation -0.5 .. -0.75 on random frontiers), and with ~4 nodes per workgroup handing out the
         // long ones first shortens the tail of a launch
@@ -3841,7 +4158,6 @@ struct hmpc_kernel_choice {
     int waves;
     int kc;  // entries per padded column of the kernel's LDS carve (Dims::kKC), 0: generic kernel
     int big; // generic kernel with lists and factor in global memory (Dims::kBig)
-    int occ2 = 0; // (a register kernel compiled at hmpc_create for two waves per SIMD, hmpc_jit.h)
 };
 // Waves per node, measured on MI355X (cart-pole N=20, ms per batch with 1 / 2 / 4 waves):
 //   8 nodes 1.81 / 1.50 / 1.41    77: 2.78 / 2.26 / 2.09    256: 2.88 / 2.47 / 2.30

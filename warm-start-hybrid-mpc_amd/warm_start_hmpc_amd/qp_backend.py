@@ -130,7 +130,7 @@ def load_library():
     return _lib
 
 
-EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_jit_stats', 'hmpc_jit_build_problem', 'hmpc_validate_kernels', 'hmpc_second_opinion_review',
+EXPORTED_SYMBOLS = ('hmpc_create', 'hmpc_destroy', 'hmpc_record_sizes', 'hmpc_launch_info', 'hmpc_kernel_info', 'hmpc_kernel_recipe', 'hmpc_jit_stats', 'hmpc_jit_build_problem', 'hmpc_validate_kernels', 'hmpc_second_opinion_review',
                     'hmpc_solve_batch', 'hmpc_solve_batch_device', 'hmpc_last_error',
                     'hmpc_set_shift_maps', 'hmpc_shift_batch', 'hmpc_shift_batch_device',
                     'hmpc_fleet_create', 'hmpc_fleet_destroy', 'hmpc_fleet_reset', 'hmpc_fleet_stop', 'hmpc_fleet_rows', 'hmpc_fleet_solve', 'hmpc_fleet_shift',
@@ -340,6 +340,15 @@ class HipBatchedQP(object):
         self.lib.hmpc_validate_kernels.restype = ctypes.c_int
         self.lib.hmpc_validate_kernels.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
         self._check(self.lib.hmpc_validate_kernels(self.handle, x0.data_ptr(), 0 if x0.dim() == 1 else self.nx, fix.data_ptr(), fix.shape[0], ctypes.c_void_p(stream)))
+
+    def kernel_recipe(self):
+        """Per wave count (1 / 2 / 4 waves per node): 1 if the compiled kernel was built with the compiler's ILP schedule -- a binary
+        listed in the cache's VALIDATED manifest --, 0 for the default schedule or a shipped kernel (``hmpc_kernel_recipe``)."""
+        k = (ctypes.c_int32 * 3)()
+        self.lib.hmpc_kernel_recipe.restype = ctypes.c_int
+        self.lib.hmpc_kernel_recipe.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]
+        self._check(self.lib.hmpc_kernel_recipe(self.handle, k))
+        return tuple(int(v) for v in k)
 
     def kernel_info(self):
         """Kind of kernel that serves this problem for 1 / 2 / 4 waves per node: 0 run-time-sized, 1 its streaming form,
