@@ -46,7 +46,7 @@ def prewarm(verbose=False, prune=False):
     if prune and os.path.isdir(cache) and paths and all(os.path.dirname(q) == cache for q in paths):
         keep = set(os.path.basename(q) for q in paths)
         for f in os.listdir(cache):
-            if f not in keep:
+            if f not in keep and f.endswith('.so'):            # (the VALIDATED manifest stays)
                 os.remove(os.path.join(cache, f))
     return paths
 
