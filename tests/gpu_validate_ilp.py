@@ -30,7 +30,7 @@ if os.environ.get('VAL_ONE'):
     from warm_start_hmpc_amd.qp_backend import HipBatchedQP, jit_prebuild
     from oracle.oracle_qp import OracleBatchedQP
     os.environ['HMPC_JIT_SELFCHECK'] = '0'
-    os.environ['HMPC_JIT_SCHED'] = 'iterative-ilp'
+    os.environ['HMPC_JIT_SCHED'] = os.environ.get('VAL_SCHED', 'iterative-ilp')   # (VAL_SCHED=default: the same run over the default recipe, report only)
     spec = eval(os.environ['VAL_ONE'])
     if isinstance(spec[0], str):
         ctrl = make_controller(spec[0], T=spec[1], terminal=spec[2], backend=_NoBackend())
@@ -101,6 +101,11 @@ for spec in CONTROLLERS + REGISTER_SHAPES + SIZED:
     print(report[-1], flush=True)
 out = os.path.join(os.path.dirname(HERE), 'gpurun_out')
 os.makedirs(out, exist_ok=True)
+if os.environ.get('VAL_SCHED', 'iterative-ilp') != 'iterative-ilp':
+    with open(os.path.join(out, 'VALIDATED.%s.report.txt' % os.environ['VAL_SCHED']), 'w') as f:
+        f.write('\n'.join(report) + '\n')
+    print('schedule %s: %d binaries pass' % (os.environ['VAL_SCHED'], len(set(valid))))
+    sys.exit(0)
 with open(os.path.join(out, 'VALIDATED'), 'w') as f:
     f.write('# binaries compiled with the ILP schedule that tests/gpu_validate_ilp.py ran against the oracle (1 / 2 / 4 waves, cold and hand-down\n'
             '# instantiation, small and large batches, a process and a watchdog each); csrc/hmpc_jit.h uses that schedule for these only\n')
