@@ -607,6 +607,10 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
             const size_t lds = hmpc_lds_bytes(p, ref.kc, ref.big);
             if (lds > lds_cu || (lds_max > 0 && lds > (size_t)lds_max)) continue;
             if (hipFuncSetAttribute((const void *)ref.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) continue;
+            if (ref.fn_warm && hipFuncSetAttribute((const void *)ref.fn_warm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError(); // (its list mode is the second opinion's launch: without it that net is off for this wave count)
+                continue;
+            }
             cf.ref = ref;
             cf.ref_lds = lds;
             int per_cu = (int)(lds_cu / lds);
