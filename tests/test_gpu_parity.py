@@ -601,6 +601,35 @@ def test_a_healthy_compiled_kernel_costs_its_second_opinion_nothing_but_two_empt
     assert a.qp.jit_stats() == (0, 1, 0) and b.qp.jit_stats() == (0, 0, 0)
 
 
+def test_the_ilp_schedule_is_only_for_validated_binaries(monkeypatch):
+    # The compiler's ILP schedule is worth 8 - 15 % and produced most of the wrong binaries of rounds 4 and 5 (one did not come back
+    # from a launch): hmpc_create uses it only for binaries listed in the cache's VALIDATED manifest (csrc/hmpc_jit.h; written by
+    # tests/gpu_validate_ilp.py), every other problem gets the compiler's default schedule.  The headline problem is in the
+    # manifest the tree ships; a random MLD nobody has validated is not; both give the oracle's records.
+    from warm_start_hmpc_amd.controller import HybridModelPredictiveController
+    from warm_start_hmpc_amd.qp_backend import HipBatchedQP
+    from oracle.oracle_qp import OracleBatchedQP
+    head = make_controller('cart_pole_with_walls', backend='hip')
+    assert head.qp.kernel_info() == (6, 6, 6) and head.qp.kernel_recipe() == (1, 1, 1), (head.qp.kernel_info(), head.qp.kernel_recipe())
+    monkeypatch.setenv('HMPC_JIT_SCHED', 'default')
+    plain = make_controller('cart_pole_with_walls', backend='hip')
+    monkeypatch.delenv('HMPC_JIT_SCHED')
+    assert plain.qp.kernel_info() == (6, 6, 6) and plain.qp.kernel_recipe() == (0, 0, 0)
+    fix = random_prefix_frontier(20, 4, 200, p_one=0.1)
+    fix[0, :] = -1
+    a, c = head.qp.solve_batch(X0, fix), plain.qp.solve_batch(X0, fix)
+    assert np.array_equal(a['status'], c['status'])
+    fin = a['status'] == 0
+    np.testing.assert_allclose(a['obj'][fin], c['obj'][fin], rtol=1e-9, atol=1e-12)
+    mld, objective, x0 = random_mld(nx=5, nuc=2, nub=2, seed=21)                      # (not among the problems of tests/jit_problems.py)
+    ctrl = HybridModelPredictiveController(mld, 9, objective, None, backend=_NoBackend())
+    new = HipBatchedQP(ctrl.problem_data())
+    assert new.kernel_info() == (6, 6, 6) and new.kernel_recipe() == (0, 0, 0), (new.kernel_info(), new.kernel_recipe())
+    f2 = random_prefix_frontier(9, 2, 128, p_one=0.3)
+    f2[0, :] = -1
+    _compare(ctrl, new.solve_batch(x0, f2), OracleBatchedQP(ctrl.problem_data(), threads=8).solve_batch(x0, f2), 9, f2, min_polished=0.99, x0=x0, efloor=1e-5)
+
+
 def test_without_a_compiler_at_run_time_the_shipped_kernels_serve(monkeypatch, tmp_path):
     # hmpc_create compiles the kernels of a problem (csrc/hmpc_jit.h); a host without the compiler -- or without the sources, or
     # with an empty cache it cannot fill -- gets the shipped kernels: built-in register kernels for the cart-pole shapes, the
