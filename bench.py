@@ -134,7 +134,7 @@ def shift_bandwidth(ctrl, dev, leaves=65536, trees=64, reps=10):
     gbs = bytes_per_leaf * B / (ms * 1e-3) / 1e9
     return {'leaves': B, 'trees': K, 'kernel_ms_avg': ms, 'algorithmic_bytes_per_leaf': bytes_per_leaf,
             'achieved_GBs': gbs, 'peak_GBs': HBM_PEAK_GBS, 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
-            'kernel': 'hmpc_shift_kernel'}
+            'kernel': 'hmpc_shift_tree_kernel + hmpc_shift_row_kernel (rows staged in LDS by global_load_lds; both launches inside the timed region)'}
 
 
 def _device_rate(qp, x0_h, fix_h, dev, reps=5, warm=2, parent=None):

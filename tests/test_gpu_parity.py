@@ -876,6 +876,40 @@ def test_device_warm_start_shift_matches_host_forms():
         assert w['solves'] < c['solves']
 
 
+@pytest.mark.parametrize('rows', ['1', '0'])
+@pytest.mark.parametrize('fixture,T', [('cart_pole_with_walls', 5), ('cart_pole_one_wall', 8), ('cart_pole_with_walls', 40)])
+def test_both_shift_kernels_on_odd_shapes(monkeypatch, fixture, T, rows):
+    # csrc/hmpc_shift.hip holds two kernels: rows staged in LDS by the memory pipeline (HMPC_SHIFT_ROWS unset / 1) and rows through
+    # registers (0; what long rows get).  Shapes the headline problem does not have: an ODD row length (with_walls N = 5: 335
+    # entries -- 8-byte stores, the last entry fetched by itself), odd counts of rows and columns of M_mu (one_wall: 19 x 27 -- a
+    # column paired with zeros), rows of 16 KB (N = 40: seven waves per CU).  Both against the per-leaf host form.
+    from warm_start_hmpc_amd.batched import BatchedMPC
+    monkeypatch.setenv('HMPC_SHIFT_ROWS', rows)
+    ctrl = make_controller(fixture, T=T, backend='hip')
+    assert ctrl.qp.n_dual % 2 == (1 if (fixture, T) == ('cart_pole_with_walls', 5) else 0)
+    bm = BatchedMPC(ctrl)
+    assert bm.device_shift
+    x_max = load_fixture(fixture)['x_max']
+    rng = np.random.RandomState(5)
+    x0s = np.array([X0 * 0.5, X0 * 0.3])
+    res = bm.feedforward_many(x0s, None, frontier_width=8)
+    assert all(np.isfinite(r['objective']) for r in res)
+    e0s = 0.01 * rng.randn(2, 4) * x_max
+    u0s = np.array([np.concatenate((r['uc'][0], r['ub'][0])) for r in res])
+    dev = bm.construct_warm_start_many([r['leaves'] for r in res], x0s, u0s, e0s)
+    for k, r in enumerate(res):
+        ref = bm.construct_warm_start(r['leaves'], x0s[k], r['uc'][0], r['ub'][0], e0s[k])
+        d = dev[k]
+        assert len(d) == len(ref) > 0
+        assert np.array_equal(d.fix, ref.fix)
+        assert np.array_equal(np.isinf(d.lb), np.isinf(ref.lb))
+        fin = np.isfinite(ref.lb)
+        np.testing.assert_allclose(d.lb[fin], ref.lb[fin], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(d.dual, ref.dual, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(d.dobj, ref.dobj, rtol=1e-10, atol=1e-12)
+        assert np.array_equal(d.has_dual, ref.has_dual)
+
+
 def test_warm_start_properties_on_gpu():
     # The reference's warm-start properties (warm_start_hmpc/test/test_controller.py:122-163) on the HIP backend: leaves
     # produced by the kernel, shifted (a) by the host form behind construct_warm_start and (b) by hmpc_shift_kernel;

@@ -63,6 +63,9 @@ struct hmpc_handle {
     int pend_cap = 0;
     void *d_shift = nullptr; // staging of the host-pointer shift
     size_t shift_staged = 0;
+    double *shift_tv = nullptr; // per tree: what the shift needs of (x0, u0) only (hmpc_shift_tree_kernel)
+    double *shift_MT2 = nullptr; // M_mu in pairs of columns, as hmpc_shift_row_kernel keeps it in LDS
+    size_t shift_tv_cap = 0;
     double *trace = nullptr;
     size_t lds = 0;
     int max_grid = 0, last_grid = 0;
@@ -694,6 +697,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->order) (void)hipFree(h->order);
     if (h->pend) (void)hipFree(h->pend);
     if (h->d_shift) (void)hipFree(h->d_shift);
+    if (h->shift_tv) (void)hipFree(h->shift_tv);
     if (h->chk) (void)hipFree(h->chk);
     if (h->hard) (void)hipFree(h->hard);
     if (h->h_hard) (void)hipHostFree(h->h_hard);
@@ -767,6 +771,21 @@ extern "C" int hmpc_set_shift_maps(hmpc_handle *h, const hmpc_shift_maps *m)
     if ((rc = upload(h, vec(m->M_mu, (size_t)p.nc * p.ncL), &p.shift_Mmu))) return rc;
     if ((rc = upload(h, vec(m->M_rho, (size_t)p.nq * p.nqT), &p.shift_Mrho))) return rc;
     if ((rc = upload(h, vec(m->V, (size_t)p.nub * p.nu), &p.shift_V))) return rc;
+    {   // [pair of columns][row] -> (column 2k, column 2k + 1), an odd last column paired with zeros
+        const size_t ncL2 = ((size_t)p.ncL + 1) / 2;
+        std::vector<double> mt(2 * ncL2 * p.nc, 0.0);
+        for (int r = 0; r < p.nc; r++)
+            for (int k = 0; k < p.ncL; k++) mt[((size_t)(k / 2) * p.nc + r) * 2 + (k & 1)] = m->M_mu[(size_t)r * p.ncL + k];
+        if (h->shift_MT2) {
+            for (auto it = h->allocs.begin(); it != h->allocs.end(); ++it)
+                if (*it == (void *)h->shift_MT2) { h->allocs.erase(it); break; }
+            (void)hipFree(h->shift_MT2);
+            h->shift_MT2 = nullptr;
+        }
+        const double *dev = nullptr;
+        if ((rc = upload(h, mt, &dev))) return rc;
+        h->shift_MT2 = (double *)dev;
+    }
     return HMPC_OK;
 }
 
@@ -795,11 +814,42 @@ extern "C" int hmpc_shift_batch_device(hmpc_handle *h, int32_t B, int32_t K, con
 static int hmpc_launch_shift(hmpc_handle *h, const ShiftArgs &a, void *stream)
 {
     const int B = a.B;
+    int cus = 0;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    {   // rows staged in LDS by the memory pipeline (hmpc_shift.hip, second kernel): one workgroup per CU, a row buffer per wave
+        const char *rows_env = getenv("HMPC_SHIFT_ROWS");   // (read per launch: the tests run both kernels in one process)
+        const bool off = rows_env && atoi(rows_env) == 0;
+        static const int cap = getenv("HMPC_SHIFT_ROW_WAVES") ? atoi(getenv("HMPC_SHIFT_ROW_WAVES")) : 0;   // (diagnostic)
+        const size_t fixed = hmpc_shift_row_fixed_doubles(h->dp), per = hmpc_shift_row_wave_doubles(h->dp), room = 160 * 1024 / sizeof(double);
+        int waves = fixed < room ? (int)((room - fixed) / per) : 0;
+        if (waves > 16) waves = 16;
+        if (cap > 0 && cap < waves) waves = cap;
+        const DevProb &q = h->dp;
+        if (!off && h->shift_MT2 && waves >= 4 && q.n_dual >= 2 && q.nub >= 1 && q.nc >= 1 && q.ncL >= 1 && q.nq >= 1 && q.nr >= 1 && q.nx >= 1) {
+            const size_t lds = (fixed + (size_t)waves * per) * sizeof(double), need_tv = (size_t)a.K * hmpc_shift_tree_doubles(q);
+            if (need_tv > h->shift_tv_cap) {   // (grows with the number of trees: the stream's earlier launches still read the old block)
+                HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+                if (h->shift_tv) (void)hipFree(h->shift_tv);
+                h->shift_tv = nullptr;
+                h->shift_tv_cap = 0;
+                HIPCHK(hipMalloc((void **)&h->shift_tv, need_tv * sizeof(double)));
+                h->shift_tv_cap = need_tv;
+            }
+            int grid = cus > 0 ? cus : 256;
+            const int need = (B + waves - 1) / waves;
+            if (grid > need) grid = need;
+            if (hipFuncSetAttribute((const void *)hmpc_shift_row_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) {
+                hipLaunchKernelGGL(hmpc_shift_tree_kernel, dim3(a.K), dim3(64), 0, (hipStream_t)stream, h->dp, a.K, a.x0, a.u0, h->shift_tv);
+                hipLaunchKernelGGL(hmpc_shift_row_kernel, dim3(grid), dim3(64 * waves), lds, (hipStream_t)stream, h->dp, a, (const double *)h->shift_tv, (const double2 *)h->shift_MT2);
+                HIPCHK(hipGetLastError());
+                return HMPC_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
     // persistent workgroups: enough to fill the device, each wave walks leaves with stride grid * SHIFT_WAVES
     const bool staged = hmpc_shift_lds_doubles(h->dp, true) * sizeof(double) <= 64 * 1024;
     const size_t lds = hmpc_shift_lds_doubles(h->dp, staged) * sizeof(double);
-    int cus = 0;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     int per_cu = (int)((160 * 1024) / (lds > 0 ? lds : 1));
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) return fail(HMPC_ETOOBIG, "the shift's last-stage vectors exceed one CU's LDS");
