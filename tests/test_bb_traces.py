@@ -13,7 +13,9 @@ Here this repository's driver (`frontier_width=1`), brancher and warm-start cons
     same arithmetic), the shifted multipliers to rounding (the reference sums the pi terms in another association);
   * on the HIP backend (GPU) the incumbent (cost, binary assignment) must be equal and the search within a few solves
     and leaves of the trace: multipliers of dependent active rows are not unique, so kernel and oracle -- like any two
-    solvers -- may meet equal bounds in another order (see the comment in _replay_case).
+    solvers -- may meet equal bounds in another order (see the comment in _replay_case).  What the HIP path does is
+    pinned exactly (HIP_PINS: the trace's own numbers on 11 of 16 steps), and where its cover has the trace's size it
+    must be the trace's cover.
 """
 import numpy as np
 import pytest
@@ -22,6 +24,19 @@ from helpers import make_controller, load_fixture
 from warm_start_hmpc_amd.branch_and_bound import best_first, depth_first
 
 CASES = ('n10', 'n10free', 'n20', 'n20depth', 'n40', 'onewall')
+# What the HIP path does on these cases, pinned (the +-3 envelope alone pinned the solve order to
+# nothing): (solves, leaves, size of the next cover) per case and step, as measured on the kernels of round 5 under BOTH
+# instruction schedules (profiles/r05_bb_deviation.txt) -- equal to the reference's trace on 11 of 16 steps (every step of n20,
+# n20depth and n40), one solve off on n10 (81 / 9 against 80 / 10), one node more on the one-wall system (157 / 102 / 100 against
+# 156 / 101 / 99, carried through its warm start), the tie of n10free.  The cause is the non-unique multipliers of dependent
+# active rows (see _replay_case); a kernel change that moves these numbers has changed which optimal multiplier the polish
+# returns somewhere, and has to say so here.
+HIP_PINS = {('n10', 0): (81, 41, 37), ('n10', 1): (9, 41, 37), ('n10', 2): (9, 41, None),
+            ('n10free', 0): (87, 45, None),
+            ('n20', 0): (160, 81, 77), ('n20', 1): (12, 81, 77), ('n20', 2): (11, 81, None),
+            ('n20depth', 0): (161, 81, 77), ('n20depth', 1): (13, 81, 77), ('n20depth', 2): (11, 81, None),
+            ('n40', 0): (320, 161, 157), ('n40', 1): (43, 162, 158), ('n40', 2): (42, 164, None),
+            ('onewall', 0): (157, 102, 100), ('onewall', 1): (147, 193, 191), ('onewall', 2): (9, 194, None)}
 RULES = {'best_first': best_first, 'depth_first': depth_first}
 
 
@@ -61,6 +76,8 @@ def _replay_case(tr, name, backend, exact):
             from kkt_checks import is_disjoint_cover
             assert abs(solves - int(tr[key + 'solves'])) <= 3, (name, s, solves, int(tr[key + 'solves']))
             assert abs(len(leaves) - len(tr[key + 'leaves_lb'])) <= 3
+            assert (solves, len(leaves)) == HIP_PINS[(name, s)][:2], (name, s, (solves, len(leaves)), 'pinned', HIP_PINS[(name, s)][:2],
+                                                                        'trace', (int(tr[key + 'solves']), len(tr[key + 'leaves_lb'])))
             assert is_disjoint_cover(ctrl, leaves)
             np.testing.assert_allclose(sol.objective, float(tr[key + 'cost']), rtol=1e-7, atol=1e-12)
             ub = np.concatenate(sol.variables['ub']).round().astype(np.int8)
@@ -77,6 +94,11 @@ def _replay_case(tr, name, backend, exact):
             np.testing.assert_allclose(np.concatenate((sol.variables['uc'][0], sol.variables['ub'][0])), u0, rtol=1e-5, atol=1e-6)
             ws, _, _ = ctrl.construct_warm_start(leaves, x, u0[:nuc], u0[nuc:], e0)
             assert abs(len(ws) - len(tr[key + 'ws_lb'])) <= 3
+            assert len(ws) == HIP_PINS[(name, s)][2], (name, s, len(ws), HIP_PINS[(name, s)][2], len(tr[key + 'ws_lb']))
+            if len(ws) == len(tr[key + 'ws_lb']):       # (where the cover has the trace's size it IS the trace's cover, and the same leaves reopen)
+                assert np.array_equal(_fix_rows(ctrl, ws), tr[key + 'ws_fix']), (name, s)
+                has_dual = np.array([n.extra.dual is not None for n in ws])
+                assert np.mean(has_dual == tr[key + 'ws_has_dual']) >= 0.98, (name, s)
             warm_start = ws
             continue
         # the reference's driver solved the same nodes in the same order ...
