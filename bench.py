@@ -411,10 +411,12 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
         fl = FleetMPC(ctrl, K, handdown=hand)
         kw = dict(frontier_width=8, speculation=spec, cold_speculation=-1 if K == 1 else spec, cold_frontier_width=2 if K == 1 else 8)
         fl.closed_loop(np.array([0., 0., 1., 0.]), 2, errs[:, :2], **kw)   # warm-up (allocations)
+        sa = fl.stats()
         cold = fl.closed_loop(np.array([0., 0., 1., 0.]), 1, errs[:, :1], **kw)
         s0 = fl.stats()
         st = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, **kw)
         s1 = fl.stats()
+        warm_only = {k: ((s1[k] - s0[k]) - (s0[k] - sa[k])) / float(steps) for k in ('rounds', 'launched', 'handed')}   # (the run of steps + 1 steps minus its cold step)
         dt = st['wall'] - cold['wall']                                                            # subtract the cold-start step
         out['fleet_%d_loops%s' % (K, '' if hand else '_no_handdown')] = {
             'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
@@ -422,6 +424,8 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
             'cold_start': 'dive prediction' if K == 1 else 'as the warm steps', 'handdown': hand, 'handed_down_verified_per_step': (s1['handed'] - s0['handed']) / (K * (steps + 1.0)),
             'cold_step_ms': 1e3 * cold['wall'], 'warm_step_ms': 1e3 * dt / steps,
             'launches_per_step_incl_cold_mean': (s1['rounds'] - s0['rounds']) / (steps + 1.0),
+            'per_warm_step': {'launches': warm_only['rounds'], 'nodes_launched_per_loop': warm_only['launched'] / K,
+                              'handed_down_verified_per_loop': warm_only['handed'] / K},
             'driver': 'hmpc_fleet_* (C++, trees behind the handle, multiplier rows resident in HBM)'}
         del fl
     out['note'] = 'closed loop sigma=0.001, warm-started B&B, frontier_width=8, reference (published, Gurobi): 26.8 steps/s'

@@ -19,7 +19,7 @@ fl = FleetMPC(ctrl, K, handdown=True)
 for run in range(3):
     fl.reset()
     xs = np.repeat(x0[None], K, axis=0)
-    ts, tsh, nodes = [], [], []
+    ts, tsh, nodes, marks = [], [], [], []
     s_prev = fl.stats()
     for t in range(steps):
         a = perf_counter()
@@ -29,9 +29,14 @@ for run in range(3):
         c = perf_counter()
         xs = r['x1'] + errs[:, t]
         ts.append(1e3 * (b - a)); tsh.append(1e3 * (c - b)); nodes.append(int(r['solves'].sum()))
+        if t in (0, steps - 1):
+            marks.append(fl.stats())
     s = fl.stats()
     sec = {k: round(s['seconds'][k] - s_prev['seconds'][k], 3) for k in s['seconds']}
     print('run %d: solve ms per step %s' % (run, ' '.join('%.1f' % v for v in ts)))
     print('        shift ms per step %s' % ' '.join('%.1f' % v for v in tsh))
+    print('        host phases of the %d warm steps, ms per step: %s; rounds per warm step %.1f' % (steps - 1, {k: round(1e3 * (marks[1]['seconds'][k] - marks[0]['seconds'][k]) / (steps - 1), 2) for k in marks[0]['seconds']},
+                                                                                                      (marks[1]['rounds'] - marks[0]['rounds']) / (steps - 1.0)))
+    print('        nodes launched per warm step %.0f, of them verified hand-downs %.0f' % ((marks[1]['launched'] - marks[0]['launched']) / (steps - 1.0), (marks[1]['handed'] - marks[0]['handed']) / (steps - 1.0)))
     print('        solves per step %s; rounds %d; phases (s) %s; warm steps/s over steps 1.. : %.0f'
           % (' '.join(str(v) for v in nodes), s['rounds'] - s_prev['rounds'], sec, K * (steps - 1) / (1e-3 * (sum(ts[1:]) + sum(tsh[1:])))), flush=True)

@@ -10,8 +10,9 @@ if os.environ.get('HMPC_LIB'):
     qb.LIBRARY_PATH = qb.LIBRARY_PATH.replace('libhmpc.so', os.environ['HMPC_LIB'])
 from helpers import make_controller
 import bench
-ctrl = make_controller('cart_pole_with_walls', backend='hip')
+T = int(os.environ.get('SHIFT_T', '20'))          # (n_dual = 45 T + 110: T = 10 and 26 give rows that are whole 128-byte lines)
+ctrl = make_controller('cart_pole_with_walls', T=T, backend='hip')
 dev = torch.device('cuda', 0)
 for leaves in (4096, 65536, 262144):
     r = bench.shift_bandwidth(ctrl, dev, leaves=leaves, reps=20)
-    print(os.environ.get('HMPC_LIB', 'libhmpc.so'), leaves, '%.3f ms' % r['kernel_ms_avg'], '%.0f GB/s' % r['achieved_GBs'], flush=True)
+    print(os.environ.get('HMPC_LIB', 'libhmpc.so'), 'T', T, 'row bytes', 8 * ctrl.qp.n_dual, leaves, '%.3f ms' % r['kernel_ms_avg'], '%.0f GB/s' % r['achieved_GBs'], flush=True)
