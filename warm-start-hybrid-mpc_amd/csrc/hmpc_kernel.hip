@@ -3605,7 +3605,10 @@ DEV int ipm_solve(const DevProb &p, const Lds &S, Rows<RS> &R, RM &rm, int lane,
                 dtau_a = dtau;
                 dkap_a = dkap;
             } else {
-                const double alpha = fmin(1.0, 0.99 * amax);
+                // fraction to the boundary: 0.99; in the END GAME of an infeasible node -- tau below kappa and falling: the step wants
+                // tau -> 0 exactly and the certificate's residual goes with tau -- it follows the barrier, 1 - max(mu, 1e-5): one iteration
+                // less on every infeasible node, optimal nodes bit for bit as before (oracle/hsde_qp.c, same place)
+                const double alpha = fmin(1.0, ((dtau < 0 && tau < kap) ? fmax(0.99, 1.0 - fmax(mu, 1e-5)) : 0.99) * amax);
                 __syncthreads();
                 for (int o = lane; o < n; o += D::kNT) S.w[o] += alpha * S.w2[o];
                 for (int o = lane; o < (T + 1) * nx; o += D::kNT) S.lam[o] += alpha * S.lam2[o];
