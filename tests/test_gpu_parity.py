@@ -704,7 +704,12 @@ def test_a_node_on_the_boundary_between_feasible_and_infeasible_is_decided(monke
     monkeypatch.delenv('HMPC_WAVES')
     b = orc.qp.solve_batch(d['x0'][0], d['fix'])
     assert a['status'][0] == 1 and b['status'][0] == 1
-    assert a['iters'][0] <= 60 and (a['weak'][0] == 1 or b['weak'][0] == 0)
+    # (which side's ray happens to verify on this node is a matter of its rounding: until the end-game fraction of round 5 the
+    # oracle's did and the kernel's was WEAK, since then the other way round at one wave per node.  A side that does not flag its
+    # ray WEAK has checked it: residual <= 1e-6 eta, eta > 0 -- a positive dual objective.)
+    assert a['iters'][0] <= 60
+    for r in (a, b):
+        assert r['weak'][0] == 1 or r['dual_obj'][0] > 0
 
 
 def test_streaming_kernel_baseline_config4():
