@@ -692,6 +692,9 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (!h) return HMPC_OK;
     if (h->dry) { delete h; return HMPC_OK; }
     (void)hipSetDevice(h->device);
+    // (work this handle issued on a caller's stream may still be in flight -- the counts of a second opinion travel to pinned
+    // memory behind an event nobody has waited for: everything on the device ends before anything is freed)
+    (void)hipDeviceSynchronize();
     for (void *d : h->allocs) (void)hipFree(d);
     if (h->rows_ws) (void)hipFree(h->rows_ws);
     if (h->order) (void)hipFree(h->order);
