@@ -418,10 +418,10 @@ def mpc_steps_per_sec(ctrl, steps=10, sims=64):
         s1 = fl.stats()
         if K >= 256:        # (a step of many loops is a handful of launches and host phases of a millisecond: the run is taken twice, the faster one counts)
             st2 = fl.closed_loop(np.array([0., 0., 1., 0.]), steps + 1, errs, **kw)
-            if st2['wall'] < st['wall']:
+            if st2['wall'] - st2['wall_first_step'] < st['wall'] - st['wall_first_step']:
                 st = st2
         warm_only = {k: ((s1[k] - s0[k]) - (s0[k] - sa[k])) / float(steps) for k in ('rounds', 'launched', 'handed')}   # (the run of steps + 1 steps minus its cold step)
-        dt = st['wall'] - cold['wall']                                                            # subtract the cold-start step
+        dt = st['wall'] - st['wall_first_step']                                                   # the warm steps of the run (its own cold start taken out)
         out['fleet_%d_loops%s' % (K, '' if hand else '_no_handdown')] = {
             'value': K * steps / dt, 'warm_solves_per_step_mean': float(st['nodes_ws'][:, 1:].mean()),
             'cover_min_max': [int(st['len_ws'].min()), int(st['len_ws'].max())], 'speculation_depth': spec,

@@ -89,7 +89,7 @@ class FleetMPC(object):
     def closed_loop(self, x0, n_steps, errors, frontier_width=8, speculation=0, cold_speculation=0, cold_frontier_width=None):
         """K closed loops from the same x0 under prescribed model errors (K, n_steps, nx) -- the shape of
         ``BatchedMPC.closed_loop(errors=...)``.  Returns dict: costs, nodes_ws, len_ws, reopened (K, n_steps; NaN / 0
-        after a loop has ended), wall, steps, steps_per_sec."""
+        after a loop has ended), wall, wall_first_step (the cold start's share of it), steps, steps_per_sec."""
         K = self.K
         errors = np.asarray(errors, dtype=np.float64)
         xs = np.repeat(np.asarray(x0, dtype=np.float64)[None], K, axis=0)
@@ -109,8 +109,10 @@ class FleetMPC(object):
             st['reopened'][:, t] = reopened
             xs = np.where(ok[:, None], r['x1'] + errors[:, t], xs)
             steps += int(ok.sum())
+            if t == 0:
+                first = perf_counter() - tic
         wall = perf_counter() - tic
-        st.update(wall=wall, steps=steps, steps_per_sec=steps / wall if wall > 0 else 0.)
+        st.update(wall=wall, wall_first_step=first if n_steps > 0 else 0., steps=steps, steps_per_sec=steps / wall if wall > 0 else 0.)
         return st
 
 
