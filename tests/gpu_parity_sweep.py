@@ -18,7 +18,7 @@ NUB, NU = hip.mld.nub, hip.mld.nu
 rng = np.random.default_rng(123)
 tot = bad_status = unpolished = 0
 worst = worst_fc = worst_tight = 0.
-nbig = nbig_tight = 0
+nbig = nbig_tight = tight_unpolished = 0
 for rep in range(int(os.environ.get('DBG_REPS', 24))):
     B = int(rng.choice([64, 300, 700, 2048, 4096]))
     p_one = float(rng.choice([0.02, 0.1, 0.3, 0.5]))
@@ -40,14 +40,20 @@ for rep in range(int(os.environ.get('DBG_REPS', 24))):
         c = tight.qp.solve_batch(x0, fix)
         xc = c['primal'][fin][:, :(T + 1) * 4]
         devt = np.max(np.abs(xa - xc), axis=1) / np.maximum(1e-2, np.max(np.abs(xc), axis=1))
-        worst_tight = max(worst_tight, float(devt.max()))
-        nbig_tight += int((devt > 1e-5).sum())
+        # (only where the tight run ends on a polished vertex: an interior-point iterate, even of gap 1e-10, is ~sqrt(gap) off in the
+        # trajectory -- rep 71 of the 96-frontier sweep: the tight run leaves one node unpolished, 5.1e-5 from the vertex that
+        # kernel and oracle both return, with an objective 4e-9 ABOVE theirs)
+        tp = c['polished'][fin] > 0
+        tight_unpolished += int((~tp).sum())
+        if tp.any():
+            worst_tight = max(worst_tight, float(devt[tp].max()))
+            nbig_tight += int((devt[tp] > 1e-5).sum())
     print('rep %2d B %4d p %.2f: status mismatches %d, not converged hip %d oracle %d, feasible %d, worst dev so far %.1e, > 1e-5: %d'
           % (rep, B, p_one, ns, int((a['status'] > 1).sum()), int((b['status'] > 1).sum()), int(fin.sum()), worst, nbig), flush=True)
 print('%s N=%d: ' % (NAME, T), end='')
 print('TOTAL nodes %d, status mismatches %d, worst state-trajectory deviation %.2e (penalised input %.2e), nodes above 1e-5: %d, optimal nodes left unpolished by the kernel: %d'
       % (tot, bad_status, worst, worst_fc, nbig, unpolished))
-print('against the tight oracle: worst deviation %.2e, nodes above 1e-5: %d' % (worst_tight, nbig_tight))
+print('against the tight oracle (where it ends polished; it leaves %d optimal nodes unpolished): worst deviation %.2e, nodes above 1e-5: %d' % (tight_unpolished, worst_tight, nbig_tight))
 
 # ---- second family: shallow prefixes, wide initial states (feasible-heavy; the nodes whose active sets need the second
 # penalty level of the polish live here), every system; the kernel against the oracle and -- independent of both --
