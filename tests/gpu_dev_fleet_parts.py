@@ -1,5 +1,5 @@
 """Diagnostic (hand-run on the GPU box): K closed loops as `parts` fleets on handles and host threads of their own
-(fleet.closed_loop_parallel): the kernel of one fleet overlaps the host bookkeeping of the others.  The time of a warm step
+(tests/parallel_fleets.py): the kernel of one fleet overlaps the host bookkeeping of the others.  The time of a warm step
 is taken from two runs of different length (fresh fleets each: allocations and the cold step cancel).
 python tests/gpu_dev_fleet_parts.py [K]"""
 import os, sys
@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import conftest  # noqa
 import numpy as np
 from helpers import make_controller, load_fixture
-from warm_start_hmpc_amd.fleet import closed_loop_parallel
+from parallel_fleets import closed_loop_parallel
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 n_short, n_long = 6, 26

@@ -1,4 +1,4 @@
-"""Diagnostic (GPU box): several fleets on several handles and host threads (fleet.closed_loop_parallel), with progress.
+"""Diagnostic (GPU box): several fleets on several handles and host threads (tests/parallel_fleets.py), with progress.
     python tests/gpu_parallel_fleets.py [loops] [steps] [parts ...]"""
 import sys
 import time
@@ -6,7 +6,8 @@ import time
 import numpy as np
 from conftest import ROOT  # noqa: F401
 from helpers import make_controller, load_fixture
-from warm_start_hmpc_amd.fleet import FleetMPC, closed_loop_parallel
+from warm_start_hmpc_amd.fleet import FleetMPC
+from parallel_fleets import closed_loop_parallel
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 6

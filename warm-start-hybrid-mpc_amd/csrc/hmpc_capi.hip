@@ -86,6 +86,7 @@ struct hmpc_handle {
     int hard_cfg = -1;            // configuration the counts in flight belong to (-1: none)
     int second_runs = 0;          // calls in which the shipped kernel was asked (for the tests)
     void *chk = nullptr;          // device block of the first-use check: 2 x HMPC_CHECK_NODES x (obj, dual_obj, status, iters)
+    void *h_chk = nullptr;        //   its PINNED host mirror (objectives, dual objectives, statuses of the three runs, the hand-down index)
     int jit_rejected = 0;         //   compiled kernels dropped by it
     std::vector<void *> jit_libs; // shared objects of kernels compiled for this problem's shape (hmpc_jit.h); never unloaded
     int jit_kernels = 0;          //   how many of the three wave counts run on such a kernel (hmpc_kernel_info)
@@ -305,6 +306,29 @@ bool hmpc_jit_prepare_sized(const DevProb &p, hmpc_cfg (&cfg)[3], std::vector<vo
 } // namespace
 
 extern "C" const char *hmpc_last_error(void) { return g_err.c_str(); }
+
+// Diagnostic (HMPC_BACKTRACE=1): the native frames of a fatal signal on stderr, then the default action.
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void hmpc_fatal_signal(int sig)
+{
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    static const char msg[] = "hmpc: fatal signal, native frames of the faulting thread:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static void hmpc_install_backtrace()
+{
+    static const bool once = [] {
+        if (getenv("HMPC_BACKTRACE")) { signal(SIGSEGV, hmpc_fatal_signal); signal(SIGABRT, hmpc_fatal_signal); signal(SIGBUS, hmpc_fatal_signal); }
+        return true;
+    }();
+    (void)once;
+}
 
 // hmpc_create; with `built` the DRY form behind hmpc_jit_build_problem: the same host code up to the choice of kernels --
 // which compiles what this problem's kernels need into the cache -- without a device: nothing is uploaded, no handle returned.
@@ -629,6 +653,15 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
             hmpc_destroy(h);
             return fail(HMPC_EDEVICE, "cannot allocate the check block");
         }
+        // (pinned: an asynchronous copy to or from pageable memory -- the stack arrays this check used until round 5 -- has the
+        // runtime register the pages for its duration, and that bookkeeping did not survive eight host threads checking their
+        // handles at once: heap corruption inside the runtime, one crash in ~30 calls of fleet.closed_loop_parallel with 8 fleets,
+        // none in 180 with the check off; profiles/r05_fleet_trace.txt)
+        if (hipHostMalloc(&h->h_chk, 3 * HMPC_CHECK_NODES * 2 * sizeof(double) + 4 * HMPC_CHECK_NODES * sizeof(int32_t), hipHostMallocDefault) != hipSuccess) {
+            h->h_chk = nullptr;
+            hmpc_destroy(h);
+            return fail(HMPC_EDEVICE, "cannot allocate the check block's host mirror");
+        }
         // second opinion of hmpc_solve_batch_device: its counts travel to two pinned words behind an event
         bool any_ref = false;
         for (int c = 0; c < 3; c++) any_ref = any_ref || h->cfg[c].ref.fn != nullptr;
@@ -669,7 +702,8 @@ static int create_impl(const hmpc_problem *q, const hmpc_options *opt, hmpc_hand
     return HMPC_OK;
 }
 
-extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out) { return create_impl(q, opt, out, nullptr); }
+extern "C" int hmpc_create(const hmpc_problem *q, const hmpc_options *opt, hmpc_handle **out) {
+    hmpc_install_backtrace(); return create_impl(q, opt, out, nullptr); }
 
 // What hmpc_create would compile for this problem -- the register kernels of its shape, or the run-time-sized kernel with
 // its sizes (hmpc_jit.h) --, compiled into the cache WITHOUT a GPU: packaging, or warming the cache of a machine without a
@@ -702,6 +736,7 @@ extern "C" int hmpc_destroy(hmpc_handle *h)
     if (h->d_shift) (void)hipFree(h->d_shift);
     if (h->shift_tv) (void)hipFree(h->shift_tv);
     if (h->chk) (void)hipFree(h->chk);
+    if (h->h_chk) (void)hipHostFree(h->h_chk);
     if (h->hard) (void)hipFree(h->hard);
     if (h->h_hard) (void)hipHostFree(h->h_hard);
     if (h->hard_done) (void)hipEventDestroy(h->hard_done);
@@ -958,8 +993,9 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
                            (const int32_t *)nullptr, w);
         HIPCHK(hipGetLastError());
     }
-    double hobj[3 * N], hdob[3 * N];
-    int32_t hst[3 * N];
+    if (!h->h_chk) return HMPC_OK;
+    double *hobj = (double *)h->h_chk, *hdob = hobj + 3 * N;   // (pinned, see hmpc_create)
+    int32_t *hst = (int32_t *)(hdob + 3 * N), *hidx = hst + 3 * N;
     HIPCHK(hipMemcpyAsync(hobj, obj, 2 * N * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(hdob, dobj, 2 * N * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(hst, st, 2 * N * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -983,9 +1019,8 @@ static int hmpc_check_compiled(hmpc_handle *h, hmpc_cfg &cf, const double *d_x0,
     // run 2: the HAND-DOWN instantiation of the compiled kernel (its own binary), every optimal node handed its own record:
     // same statuses, same objectives, and a polished node's active set verifies without an interior-point iteration
     if (same && cf.k.fn_warm) {
-        int32_t hidx[N];
         for (int b = 0; b < N; b++) hidx[b] = hst[N + b] == HMPC_OPTIMAL ? b : -1;
-        HIPCHK(hipMemcpyAsync(idx, hidx, sizeof hidx, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(idx, hidx, N * sizeof(int32_t), hipMemcpyHostToDevice, stream));
         const DevWarm ww{prim, dual, idx, nullptr, 0};
         const DevOut o{obj + 2 * N, dobj + 2 * N, st + 2 * N, it + 2 * N, nullptr, nullptr};
         HIPCHK(hipMemsetAsync(h->dp.work_counter, 0, sizeof(int), stream));

@@ -116,42 +116,6 @@ class FleetMPC(object):
         return st
 
 
-def closed_loop_parallel(controller, x0, n_steps, errors, parts=2, **kwargs):
-    """K closed loops as ``parts`` fleets of K / parts loops, each on a library handle and a host thread of its own.
-
-    One fleet alternates between host bookkeeping (selection, prune / branch, staging) and a kernel launch, so at many
-    loops the GPU idles while the host works and vice versa.  Independent loops need no lockstep between fleets: with
-    several fleets in flight the kernel of one overlaps the bookkeeping of the others (the C calls release the
-    interpreter lock; every handle has its own stream and workspaces, include/hmpc.h: one launch in flight per handle).
-    Returns the dictionary of ``FleetMPC.closed_loop`` with the per-loop arrays in the order of ``errors``; ``wall`` is
-    the time until the last fleet has finished."""
-    import copy
-    from concurrent.futures import ThreadPoolExecutor
-    from .qp_backend import HipBatchedQP
-    errors = np.asarray(errors, dtype=np.float64)
-    K = errors.shape[0]
-    parts = max(1, min(int(parts), K))
-    bounds = [(K * j) // parts for j in range(parts + 1)]
-    fleets = []
-    for j in range(parts):
-        c = controller if j == 0 else copy.copy(controller)
-        if j:
-            params = dict(controller.solver_params)
-            params.setdefault('device', controller.qp.device)
-            c.qp = HipBatchedQP(controller.problem_data(), **params)
-        fleets.append(FleetMPC(c, bounds[j + 1] - bounds[j], handdown=kwargs.pop('handdown', True) if j == 0 else fleets[0].handdown))
-    tic = perf_counter()
-    with ThreadPoolExecutor(max_workers=parts) as pool:
-        runs = list(pool.map(lambda j: fleets[j].closed_loop(x0, n_steps, errors[bounds[j]:bounds[j + 1]], **kwargs), range(parts)))
-    wall = perf_counter() - tic
-    st = {k: np.concatenate([r[k] for r in runs]) for k in ('costs', 'nodes_ws', 'len_ws', 'reopened')}
-    steps = sum(r['steps'] for r in runs)
-    stats = [f.stats() for f in fleets]
-    st.update(wall=wall, steps=steps, steps_per_sec=steps / wall if wall > 0 else 0., parts=parts,
-              rounds=sum(s['rounds'] for s in stats), launched=sum(s['launched'] for s in stats), handed=sum(s['handed'] for s in stats))
-    return st
-
-
 def closed_loop_study(controller, x0, errors, frontier_width=1, cold_too=True, speculation=0, log=None, sim_ids=None,
                       handdown=True):
     """The reference's closed-loop study (``notebooks/cart_pole_with_walls/statistical_analysis.py:93-196``) on the fleet
